@@ -1,0 +1,104 @@
+"""The oracle (oracle/loss.py, oracle/scheduler.py) against the reference's own outputs.
+
+Goldens under tests/golden/ were produced by oracle/make_golden.py running the reference's
+src/duwu/loss/*.py; known-answer constants come from the reference's configs / notebook
+(SURVEY.md section 4).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import loss as OL
+from oracle.scheduler import (EulerDiscreteScheduler, cosine_logsnr, laplace_logsnr, logsnr_to_sigmas)
+from tests.golden_util import load, names
+
+
+def close(a, b, rtol=2e-6, atol=1e-6):
+    torch.testing.assert_close(a, b, rtol=rtol, atol=atol)
+
+
+def test_sigma_max_pin():
+    # configs/sampling/demo_sampling.yaml:49 -> 14.6146
+    s = EulerDiscreteScheduler.sdxl()
+    assert abs(s.sigmas[0].item() - 14.6146) < 5e-5
+    assert abs(s.sigmas[-2].item() - 0.029167533) < 1e-8
+    assert s.sigmas[-1].item() == 0.0 and s.sigmas.shape == (1001,)
+    assert s.timesteps[0].item() == 999.0 and s.timesteps[-1].item() == 0.0
+
+
+def test_notebook_laplace_pin():
+    # test_scripts/test_diffusion_scheduler.ipynb cell 2 stored output (b = 1.5 run)
+    t = np.linspace(0, 1, 1002)[1:-1]
+    sig, _ = logsnr_to_sigmas(laplace_logsnr(t, 0, 1.5, float(np.finfo(np.float32).eps)))
+    assert f"{min(sig):.9f}" == "0.009449642" and f"{max(sig):.6f}" == "105.811714" and int(np.sum(sig >= 10)) == 23
+
+
+def test_notebook_table_pin():
+    # notebook cell 5 stored output
+    t = np.linspace(0, 1, 1000)
+    exp_l = [(8191.996, 1), (67108804.0, 5), (549755600000.0, 24), (4503591300000000.0, 50)]
+    for b, (mx, cnt) in zip((0.5, 1.0, 1.5, 2.0), exp_l):
+        sig, _ = logsnr_to_sigmas(laplace_logsnr(t, 0, b))
+        assert np.isclose(max(sig), mx, rtol=1e-6) and int(sum(sig >= 10)) == cnt
+    exp_c = [(28519397000000.0, 195), (5340355.5, 64), (30552.502, 21), (2310.9211, 7)]
+    for s_, (mx, cnt) in zip((0.5, 1.0, 1.5, 2.0), exp_c):
+        sig, _ = logsnr_to_sigmas(cosine_logsnr(t, s=s_))
+        assert np.isclose(max(sig), mx, rtol=1e-6) and int(sum(sig >= 10)) == cnt
+
+
+def test_tables_golden():
+    _, d = load("tables")
+    s = EulerDiscreteScheduler.sdxl()
+    close(OL.all_snr(s), d["all_snr"], rtol=0, atol=0)
+    close(s.sigmas, d["sigmas"], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("name", names("dl_"))
+def test_diffusion_loss_golden(name):
+    meta, d = load(name)
+    kw = dict(meta["kwargs"])
+    s = EulerDiscreteScheduler.sdxl()
+    o = OL.diffusion_loss(s, d["x"], d["noise"], d["timesteps"], lambda n, t: d["model_output"], **kw)
+    close(o.sigmas, d["sigmas"], rtol=0, atol=0)
+    close(o.noisy_latent, d["noisy"])
+    close(o.target, d["target"])
+    close(o.pred, d["pred"], rtol=1e-5, atol=1e-5)
+    close(o.losses, d["losses"], rtol=1e-5, atol=1e-7)
+    close(o.loss, d["loss"], rtol=1e-5, atol=1e-7)
+    close(o.dloss_dout, d["dloss_dout"], rtol=2e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", names("rf_"))
+def test_rf_loss_golden(name):
+    meta, d = load(name)
+    kw = dict(meta["kwargs"])
+    s = EulerDiscreteScheduler.sdxl(prediction_type=meta["prediction_type"])
+    sig = OL.rf_time_to_sigma(s, d["u01"])
+    close(sig, d["sigmas"], rtol=0, atol=0)
+    o = OL.rectified_flow_loss(s, d["x"], d["noise"], sig, lambda n, t: d["model_output"], **kw)
+    close(o.timesteps, d["timesteps"], rtol=0, atol=0)
+    close(o.noisy_latent, d["noisy"])
+    close(o.target, d["target"])
+    close(o.pred, d["pred"], rtol=1e-5, atol=1e-5)
+    close(o.losses, d["losses"], rtol=1e-5, atol=1e-7)
+    close(o.loss, d["loss"], rtol=1e-5, atol=1e-7)
+    close(o.dloss_dout, d["dloss_dout"], rtol=2e-5, atol=1e-7)
+
+
+def test_sigma_to_timestep_golden():
+    _, d = load("sigma_to_timestep")
+    s = EulerDiscreteScheduler.sdxl()
+    close(OL.sigma_to_timestep(s, d["sigmas"]), d["timesteps"], rtol=0, atol=0)
+
+
+def test_analytic_grad_matches_autograd():
+    torch.manual_seed(3)
+    s = EulerDiscreteScheduler.sdxl()
+    x, n = torch.randn(3, 4, 8, 8), torch.randn(3, 4, 8, 8)
+    t = torch.tensor([5, 500, 999])
+    for p in OL.PRED_TYPES:
+        for tt in OL.PRED_TYPES:
+            out = torch.randn(3, 4, 8, 8, requires_grad=True)
+            o = OL.diffusion_loss(s, x, n, t, lambda a, b: out, prediction_type=p, target_type=tt)
+            (g,) = torch.autograd.grad(o.loss, out)
+            close(o.dloss_dout, g, rtol=1e-4, atol=1e-7)
