@@ -1,0 +1,203 @@
+/*
+ * uwu_hip.h -- C ABI of libuwu_hip.so: the MI355X (gfx950) kernels behind the `duwu`
+ * training inner loop.
+ *
+ * The reference (KohakuBlueleaf/UwUDiff) has NO FFI on this path: its boundary is a Python
+ * plugin slot (`instantiate_any`, reference src/duwu/utils/__init__.py:41-50; `load_any`,
+ * src/duwu/loader.py:58-67).  Each entry below therefore cites the reference *Python* lines
+ * whose torch/diffusers op sequence it replaces; INTEGRATION.md shows the ctypes binding a
+ * maintainer adds on the reference side.
+ *
+ * Conventions:
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch tensors' data_ptr());
+ *   - no entry allocates, frees or synchronises; work is enqueued on `stream` (a hipStream_t
+ *     passed as void*);
+ *   - return 0 on success, a negative UWU_E* code otherwise; uwu_last_error() gives the text;
+ *   - `dtype` arguments: UWU_F32 = 0, UWU_BF16 = 1 (storage type of the activation operands;
+ *     accumulation, statistics, loss and optimizer state are always fp32).
+ */
+#ifndef UWU_HIP_H
+#define UWU_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UWU_F32 0
+#define UWU_BF16 1
+
+#define UWU_OK 0
+#define UWU_EINVAL (-1)   /* bad argument / unsupported shape */
+#define UWU_ELAUNCH (-2)  /* hipLaunch error */
+#define UWU_ENOTIMPL (-3)
+
+/* prediction / target parameterisations (reference src/duwu/loss/diffusion.py:84-125) */
+#define UWU_PT_EPSILON 0
+#define UWU_PT_V 1
+#define UWU_PT_SAMPLE 2
+#define UWU_PT_RF 3
+
+/* GEMM epilogues */
+#define UWU_EPI_NONE 0
+#define UWU_EPI_BIAS 1       /* C = A.B + bias[n]                                        */
+#define UWU_EPI_BIAS_GELU 2  /* C = A.B + bias ; C2 = gelu_tanh(C)   (fc1 forward)       */
+#define UWU_EPI_DGELU 3      /* C = (A.B) * gelu_tanh'(aux[m,n])     (fc2 dgrad -> dU)   */
+#define UWU_EPI_BIAS_SILU 4  /* C = silu(A.B + bias)                 (timestep MLP)      */
+#define UWU_EPI_ACCUM 5      /* C += A.B  (fp32 C only; wgrad accumulation, split-K)     */
+
+const char* uwu_last_error(void);
+int uwu_version(void);
+
+/* ------------------------------------------------------------------ objective (a1-a10) */
+
+/* Per-sample schedule gather: replaces the Python loops at diffusion.py:58 (B x nonzero().item()),
+ * :146 and :159-161.  coef[b] = {sigma_b, weight_b, sqrt(abar_t), sqrt(1-abar_t)}.
+ *   sigma_b  = sigmas_desc[N-1-t_b]                         (diffusion.py:53-62)
+ *   weight_b = [min(snr,gamma)/snr | /(snr+1) for v]  x  [1/sqrt(min(snr,1000))]   (:141-167)
+ * snr_mode: 0 none, 1 epsilon form, 2 v form; debias: 0/1. */
+int uwu_schedule_gather(const int64_t* timesteps, const float* sigmas_desc, const float* all_snr,
+                        const float* alphas_cumprod, int n_train, int B, int snr_mode, float gamma,
+                        int debias, float* coef, void* stream);
+
+/* Rectified-flow time sampling: rectified_flow.py:29-42 and sigma_to_timestep :98-129.
+ *   time = u01*smax/(1+smax); sigma = time/(1-time); timesteps = log-sigma piecewise-linear inverse
+ * over log_sigmas_asc[n_train] (ascending log of sigmas[:-1] flipped).  coef[b] = {sigma,1,0,0}. */
+int uwu_rf_time_to_sigma(const float* u01, float sigma_max, const float* log_sigmas_asc, int n_train,
+                         int B, float* coef, float* timesteps, void* stream);
+
+/* Forward process, diffusion.py:77-82 / rectified_flow.py:67-71:
+ *   noisy = (x + noise*sigma_b) * (sigma_b^2+1)^-1/2 ; fp32 out and (optional, may be NULL) bf16 copy.
+ * n = elements per sample. */
+int uwu_qsample(const float* x, const float* noise, const float* coef, int B, int64_t n, float* noisy,
+                void* noisy_bf16, void* stream);
+
+/* Fused prediction conversion + target + per-sample weighted MSE + d loss/d model_output,
+ * diffusion.py:177-193 (+ :100-139) and rectified_flow.py:79-96.
+ *   xt: the tensor the reference passes as `xt` (clean x for DiffusionLoss :177, noisy for RF :80).
+ *   out_dtype: dtype of model_output and of grad_out.
+ *   pred/target may be NULL (aux outputs).  losses[b] = w_b * mean((pred-target)^2);
+ *   grad_out = d mean_b(losses) / d model_output.  force_convert=1 is the RF path (always converts). */
+int uwu_loss_fwd_bwd(const float* x, const float* noise, const float* xt, const void* model_output,
+                     int out_dtype, const float* coef, int pred_type, int target_type, int force_convert,
+                     int B, int64_t n, float* losses, float* loss_mean, void* grad_out, float* pred,
+                     float* target, void* stream);
+
+/* y[i] *= *scale (device scalar); used when autograd hands a non-unit upstream gradient. */
+int uwu_scale_inplace(void* y, int dtype, int64_t n, const float* scale, void* stream);
+
+/* ------------------------------------------------------------------ optimizer (a15) */
+
+/* Global L2 norm of a flat fp32 buffer (Lightning gradient_clip_val, demo_training.yaml:12):
+ * out[0] = sum(g^2) * pre_scale^2 ; out[1] = clip coefficient min(1, max_norm/(sqrt(out[0])+1e-6))
+ * (max_norm <= 0 -> 1).  partial: workspace of >= 1024 floats. */
+int uwu_grad_sqnorm_clip(const float* g, int64_t n, float pre_scale, float max_norm, float* partial,
+                         float* out, void* stream);
+
+/* torch.optim.AdamW single-tensor semantics (trainer.py:52-74, demo_training_latent.yaml:30-39) on flat
+ * buffers; g_eff = g * pre_scale * clip[1] (clip may be NULL).  Also refreshes the bf16 shadow
+ * (may be NULL).  step is the 1-based step count. */
+int uwu_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int step, float pre_scale,
+                   const float* clip, void* stream);
+
+int uwu_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+int uwu_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------ dense contractions (a11-a13) */
+
+/* C[M,N] = opA(A) . opB(B)  (+ epilogue), fp32 accumulate on MFMA.
+ *   transA=0: A is [M,K] row-major (lda);  transA=1: A is [K,M] row-major (lda).
+ *   transB=0: B is [N,K] row-major (ldb) -- torch Linear weight layout; transB=1: B is [K,N] (ldb).
+ *   dtype: operand storage (UWU_F32 -> v_mfma_f32_16x16x4_f32, UWU_BF16 -> v_mfma_f32_16x16x32_bf16).
+ *   c_dtype: storage of C / C2 (bf16 or fp32).  bias fp32[N].  aux: [M,N] operand-dtype tensor (ldaux).
+ *   split_k > 1 requires UWU_EPI_ACCUM with fp32 C (atomic accumulation).
+ * Replaces nn.Linear forward / dgrad / wgrad inside the denoiser (rope_unet.py:122-166). */
+int uwu_gemm(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux,
+             int M, int N, int K, int lda, int ldb, int ldc, int ldaux, int transA, int transB, int dtype,
+             int c_dtype, int epilogue, int split_k, void* stream);
+
+/* out[n] (+)= sum_m X[m,n]   (bias gradients). accumulate: 0 overwrite, 1 add. */
+int uwu_colsum(const void* X, int dtype, int M, int N, int ldx, float* out, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------ norms / modulation (a13) */
+
+/* adaLN-Zero pre-norm with fused residual update (rope_unet.py:306-309, 344-349, 393-411):
+ *   x_out = x_in + gate_b * y            (y/gate may be NULL: x_out = x_in, not written if x_out==x_in)
+ *   h     = LayerNorm(x_out; eps, no affine) * (1 + scale_b) + shift_b
+ * x_*, y, h: [B*T, D] in `dtype`; shift/scale/gate: fp32 rows of a [B, mod_ld] buffer; mean/rstd fp32[B*T]. */
+int uwu_add_ln_modulate_fwd(const void* x_in, const void* y, const float* gate, const float* shift,
+                            const float* scale, int mod_ld, void* x_out, void* h, float* mean, float* rstd,
+                            int B, int T, int D, float eps, int dtype, void* stream);
+
+/* Backward of the above, fused with the residual/gate backward of the branch that feeds x:
+ *   dx_out = dx_in + LN_bwd(dh * (1+scale_b))        (dx_in may be NULL for the last norm)
+ *   dy     = gate_b * dx_out                          (if y given)
+ *   dshift_b += sum_t dh ; dscale_b += sum_t dh*xhat ; dgate_b += sum_t dx_out*y   (fp32 atomics)
+ * dmod rows live in a zero-initialised [B, mod_ld] fp32 buffer. */
+int uwu_add_ln_modulate_bwd(const void* dh, const void* x, const float* mean, const float* rstd,
+                            const float* scale, const void* dx_in, const void* y, const float* gate,
+                            int mod_ld, void* dx_out, void* dy, float* dshift, float* dscale, float* dgate,
+                            int B, int T, int D, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ attention (a12) */
+
+/* softmax(Q K^T / sqrt(d)) V over packed qkv [B*T, 3*H*d] (q | k | v, heads contiguous inside each),
+ * non-causal, no mask (rope_unet.py:151-153 F.scaled_dot_product_attention).  o: [B*T, H*d];
+ * lse: fp32 [B,H,T] (log-sum-exp of scaled scores), saved for backward. */
+int uwu_attention_fwd(const void* qkv, void* o, float* lse, int B, int T, int H, int d, int dtype,
+                      void* stream);
+/* dqkv [B*T, 3*H*d] from (qkv, o, do, lse).  delta: fp32 workspace [B,H,T]. */
+int uwu_attention_bwd(const void* qkv, const void* o, const void* dO, const float* lse, float* delta,
+                      void* dqkv, int B, int T, int H, int d, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ embeddings / layout (a11, a13) */
+
+/* Sinusoidal timestep features [B, dim]: [cos(t*f_i) | sin(t*f_i)], f_i = exp(-ln(max_period)*i/half). */
+int uwu_timestep_embedding(const float* t, int B, int dim, float max_period, void* out, int dtype,
+                           void* stream);
+/* y = silu(x) elementwise (dtype in/out); dx = dy * silu'(x). */
+int uwu_silu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream);
+int uwu_silu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dtype, void* stream);
+
+/* patchify: latent [B,C,H,W] (fp32) -> tokens [B*(H/p)*(W/p), C*p*p] (dtype), feature order (c,ph,pw).
+ * unpatchify is the inverse (tokens -> fp32 image).  Conv2d(k=p,s=p) patch embedding == patchify + GEMM. */
+int uwu_patchify(const float* img, void* tok, int B, int C, int H, int W, int p, int dtype, void* stream);
+int uwu_unpatchify(const void* tok, int dtype, float* img, int B, int C, int H, int W, int p, void* stream);
+/* x[b,t,:] += pos[t,:]  (fixed 2-D sin-cos table, fp32 [T,D]) */
+int uwu_add_pos(void* x, const float* pos, int B, int T, int D, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ whole-network drivers */
+
+/* DiT forward/backward: all kernel launches of one network pass issued from C++ (no per-op
+ * host round trip).  The argument block is a plain C struct of device pointers and sizes. */
+typedef struct uwu_dit_desc {
+  int32_t B, T, D, H, L, mlp_ratio, in_ch, out_ch, patch, img, dtype, cond_dim;
+  float ln_eps;
+  int32_t mod_total;   /* = L*6*D + 2*D : all adaLN linears batched in one GEMM */
+  /* parameter blob (operand dtype copy for GEMM operands, fp32 master for biases) */
+  const void* w;        /* operand-dtype flat parameters  */
+  const float* w32;     /* fp32 master flat parameters    */
+  float* g32;           /* fp32 flat gradient buffer (accumulated into) */
+  /* offsets (in elements) into the flat blobs */
+  int64_t off_patch_w, off_patch_b, off_t_w1, off_t_b1, off_t_w2, off_t_b2, off_y_w, off_y_b,
+      off_mod_w, off_mod_b, off_final_w, off_final_b;
+  int64_t off_layer0, layer_stride; /* per layer: qkv_w, qkv_b, o_w, o_b, fc1_w, fc1_b, fc2_w, fc2_b */
+  const float* pos;     /* [T, D] fp32 */
+  void* ws;             /* activation workspace (saved for backward) */
+  size_t ws_bytes;
+} uwu_dit_desc;
+
+size_t uwu_dit_workspace_bytes(const uwu_dit_desc* d);
+/* noisy: fp32 [B,C,H,W]; t: fp32 [B]; cond: fp32 [B, cond_dim] or NULL; out: fp32 [B,out_ch,H,W] */
+int uwu_dit_forward(const uwu_dit_desc* d, const float* noisy, const float* t, const float* cond,
+                    float* out, void* stream);
+/* dout: `fp32` [B,out_ch,H,W] gradient of the loss wrt the network output. */
+int uwu_dit_backward(const uwu_dit_desc* d, const float* dout, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UWU_HIP_H */

@@ -1,0 +1,173 @@
+"""GPU parity: HIP objective kernels (through the C ABI) vs the reference-generated goldens and the oracle.
+
+Tolerance: fp32 path, 1e-3 relative is the north-star bar; these kernels follow the reference's op order
+and land ~1e-6, so the tests assert a much tighter 2e-5.
+"""
+import pytest
+import torch
+
+from tests.golden_util import load, names
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 2e-5, 2e-6
+
+
+def close(a, b, rtol=RTOL, atol=ATOL):
+    torch.testing.assert_close(a.detach().float().cpu(), b, rtol=rtol, atol=atol)
+
+
+class LeafUNet(torch.nn.Module):
+    def __init__(self, out):
+        super().__init__()
+        self.out = out
+
+    def forward(self, noisy, timesteps, **kw):
+        return (self.out,)
+
+
+def _sched(**kw):
+    from uwudiff_amd.scheduler import EulerDiscreteScheduler
+
+    return EulerDiscreteScheduler.from_pretrained("stabilityai/stable-diffusion-xl-base-1.0", subfolder="scheduler", **kw)
+
+
+@pytest.mark.parametrize("name", names("dl_"))
+def test_diffusion_loss_vs_reference_golden(name):
+    from uwudiff_amd.objective import DiffusionLoss
+
+    meta, d = load(name)
+    dev = "cuda"
+    mod = DiffusionLoss(_sched(), **meta["kwargs"])
+    out = d["model_output"].to(dev).requires_grad_(True)
+    mod.inject(noise=d["noise"].to(dev), timesteps=d["timesteps"].to(dev))
+    loss, aux = mod(d["x"].to(dev), LeafUNet(out))
+    loss.backward()
+    close(aux.noisy_latent, d["noisy"])
+    close(aux.target, d["target"])
+    close(aux.pred, d["pred"], rtol=1e-4, atol=1e-4)  # 1/sigma conversions amplify rounding
+    close(aux.losses, d["losses"], rtol=1e-4, atol=1e-7)
+    close(loss, d["loss"], rtol=1e-4, atol=1e-7)
+    close(out.grad, d["dloss_dout"], rtol=2e-4, atol=1e-7)
+    assert torch.equal(aux.timesteps.cpu(), d["timesteps"])
+
+
+@pytest.mark.parametrize("name", names("rf_"))
+def test_rf_loss_vs_reference_golden(name):
+    from uwudiff_amd.objective import RectifiedFlowLoss
+
+    meta, d = load(name)
+    dev = "cuda"
+    mod = RectifiedFlowLoss(scheduler=_sched(prediction_type=meta["prediction_type"]), **meta["kwargs"])
+    out = d["model_output"].to(dev).requires_grad_(True)
+    mod.inject(u01=d["u01"].to(dev))
+    x5 = torch.stack([d["x"], d["noise"]], dim=1).to(dev)
+    loss, aux = mod(x5, LeafUNet(out))
+    loss.backward()
+    close(aux.timesteps, d["timesteps"], rtol=1e-5, atol=1e-3)
+    close(aux.noisy_latent, d["noisy"], rtol=1e-4, atol=1e-5)
+    close(aux.target, d["target"], rtol=1e-4, atol=1e-5)
+    close(aux.pred, d["pred"], rtol=2e-4, atol=2e-4)
+    close(aux.losses, d["losses"], rtol=2e-4, atol=1e-7)
+    close(loss, d["loss"], rtol=2e-4, atol=1e-7)
+    close(out.grad, d["dloss_dout"], rtol=5e-4, atol=1e-7)
+
+
+def test_sigma_to_timestep_golden():
+    from uwudiff_amd import lib as L
+    from uwudiff_amd.objective import RectifiedFlowLoss
+
+    _, d = load("sigma_to_timestep")
+    mod = RectifiedFlowLoss(scheduler=_sched())
+    smax = float(mod.scheduler.sigmas[0])
+    sig = d["sigmas"]
+    time = sig / (1 + sig)
+    u = (time / (smax / (1 + smax))).clamp(max=1.0).cuda()
+    mod.inject(u01=u)
+    t, coef = mod.sample_timesteps_and_sigmas(torch.zeros(len(sig), 1, device="cuda"))
+    sig_dev = coef[:, 0].cpu()
+    # compare at the sigmas the kernel actually derived from u01
+    from oracle import loss as OL
+    from oracle.scheduler import EulerDiscreteScheduler as OS
+
+    ref = OL.sigma_to_timestep(OS.sdxl(), sig_dev)
+    close(t, ref, rtol=1e-5, atol=2e-3)
+
+
+def test_uniform_sampling_statistics():
+    """Without injection the kernels draw on-device: timesteps uniform on {0..999}, loss finite."""
+    from uwudiff_amd.objective import DiffusionLoss
+
+    torch.manual_seed(0)
+    mod = DiffusionLoss(_sched())
+    x = torch.randn(4096, 4, 2, 2, device="cuda")
+    t, coef = mod.sample_timesteps_and_sigmas(x)
+    assert t.min().item() >= 0 and t.max().item() <= 999
+    assert abs(t.float().mean().item() - 499.5) < 25
+    sig = mod.scheduler.sigmas[999 - t.cpu()]
+    close(coef[:, 0], sig, rtol=0, atol=0)
+
+
+def test_error_behaviour_matches_reference():
+    from uwudiff_amd.objective import DiffusionLoss, RectifiedFlowLoss
+
+    x = torch.randn(2, 4, 8, 8, device="cuda")
+    u = LeafUNet(torch.randn(2, 4, 8, 8, device="cuda"))
+    with pytest.raises(ValueError):  # diffusion.py:98
+        DiffusionLoss(_sched(), target_type="bogus")(x, u)
+    with pytest.raises(ValueError):  # diffusion.py:124
+        DiffusionLoss(_sched(), prediction_type="bogus", target_type="epsilon")(x, u)
+    with pytest.raises(AssertionError):  # diffusion.py:143-144
+        DiffusionLoss(_sched(), use_snr_weight=True, prediction_type="sample", target_type="sample")(x, u)
+    with pytest.raises(AssertionError):  # diffusion.py:157
+        DiffusionLoss(_sched(), use_debiased_estimation=True, prediction_type="v_prediction",
+                      target_type="v_prediction")(x, u)
+    with pytest.raises(ValueError):  # rectified_flow.py:44-47
+        RectifiedFlowLoss(scheduler=_sched(), time_sampling_type="bogus")(x, u)
+
+
+def test_bf16_model_output_and_upstream_scale():
+    from oracle import loss as OL
+    from oracle.scheduler import EulerDiscreteScheduler as OS
+    from uwudiff_amd.objective import DiffusionLoss
+
+    torch.manual_seed(1)
+    x, n = torch.randn(8, 4, 16, 16), torch.randn(8, 4, 16, 16)
+    t = torch.randint(0, 1000, (8,))
+    out_bf = torch.randn(8, 4, 16, 16).bfloat16()
+    o = OL.diffusion_loss(OS.sdxl(), x, n, t, lambda a, b: out_bf.float())
+    mod = DiffusionLoss(_sched())
+    out = out_bf.cuda().requires_grad_(True)
+    mod.inject(noise=n.cuda(), timesteps=t.cuda())
+    loss, aux = mod(x.cuda(), LeafUNet(out))
+    (loss * 3.0).backward()
+    close(loss, o.loss, rtol=1e-5, atol=1e-7)
+    close(out.grad, (3.0 * o.dloss_dout).bfloat16().float(), rtol=1.6e-2, atol=1e-6)
+
+
+def test_adamw_and_clip_vs_torch():
+    """Flat fused AdamW + global-norm clip vs torch.optim.AdamW + clip_grad_norm_ on CPU (trainer.py:52-74)."""
+    from uwudiff_amd import lib as L
+
+    torch.manual_seed(0)
+    n = 100_003
+    p0 = torch.randn(n)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref], lr=1e-3, weight_decay=0.01, betas=(0.9, 0.999))
+    p = p0.clone().cuda()
+    m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    pbf = torch.empty(n, device="cuda", dtype=torch.bfloat16)
+    part, out = torch.empty(1024, device="cuda"), torch.empty(2, device="cuda")
+    for step in range(1, 6):
+        g = torch.randn(n) * (10.0 if step % 2 else 0.001)
+        ref.grad = g.clone()
+        tn = torch.nn.utils.clip_grad_norm_([ref], 1.0)
+        opt.step()
+        gd = g.cuda()
+        L.call("uwu_grad_sqnorm_clip", L.ptr(gd), n, 1.0, 1.0, L.ptr(part), L.ptr(out), L.stream())
+        L.call("uwu_adamw_step", L.ptr(p), L.ptr(gd), L.ptr(m), L.ptr(v), L.ptr(pbf), n, 1e-3, 0.9, 0.999, 1e-8,
+               0.01, step, 1.0, L.ptr(out), L.stream())
+        close(out[0].sqrt(), tn, rtol=1e-5, atol=0)
+        close(p, ref.data, rtol=1e-5, atol=1e-6)
+    close(pbf, ref.data.bfloat16().float(), rtol=8e-3, atol=1e-6)
+    close(m, opt.state[ref]["exp_avg"], rtol=1e-5, atol=1e-7)
+    close(v, opt.state[ref]["exp_avg_sq"], rtol=1e-5, atol=1e-9)

@@ -1,0 +1,113 @@
+// Shared device/host helpers for libuwu_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/uwu_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define UWU_WAVE 64
+
+// ---- error plumbing (host) -------------------------------------------------------------
+void uwu_set_error(const char* fmt, ...);
+
+#define UWU_CHECK_ARG(cond, ...)       \
+  do {                                 \
+    if (!(cond)) {                     \
+      uwu_set_error(__VA_ARGS__);      \
+      return UWU_EINVAL;               \
+    }                                  \
+  } while (0)
+
+#define UWU_LAUNCH_CHECK(name)                                                  \
+  do {                                                                          \
+    hipError_t e_ = hipGetLastError();                                          \
+    if (e_ != hipSuccess) {                                                     \
+      uwu_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));      \
+      return UWU_ELAUNCH;                                                       \
+    }                                                                           \
+  } while (0)
+
+// ---- scalar conversions -----------------------------------------------------------------
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+template <typename T>
+__device__ __forceinline__ T from_f32(float v);
+template <>
+__device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }  // RNE, NaN-safe (v_cvt_pk_bf16_f32)
+
+// ---- wave / block reductions ------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// sum over a block of NW waves; result valid in every thread. `red` = NW floats of LDS.
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) t += red[i];
+  return t;
+}
+
+// ---- vector load/store of 4 consecutive elements as fp32 ---------------------------------
+__device__ __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 load4(const bf16_t* p) {
+  bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+  return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ __forceinline__ void store4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void store4(bf16_t* p, f32x4 v) {
+  bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+  *reinterpret_cast<bf16x4*>(p) = o;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+__device__ __forceinline__ float dsilu_f(float x) {
+  float s = 1.f / (1.f + __expf(-x));
+  return s * (1.f + x * (1.f - s));
+}
+// tanh-approximate GELU (DiT / diffusers "gelu-approximate")
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float u = k0 * (x + k1 * x * x * x);
+  float t = 1.f - 2.f / (1.f + __expf(2.f * u));  // tanh(u)
+  return 0.5f * x * (1.f + t);
+}
+__device__ __forceinline__ float dgelu_tanh_f(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float u = k0 * (x + k1 * x * x * x);
+  float t = 1.f - 2.f / (1.f + __expf(2.f * u));
+  float du = k0 * (1.f + 3.f * k1 * x * x);
+  return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * du;
+}
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+// elementwise launch: cap at 256 CUs x 8 blocks and grid-stride the rest
+static inline int ew_grid(int64_t work, int block) {
+  int64_t g = (work + block - 1) / block;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
+}

@@ -1,0 +1,359 @@
+// MFMA GEMM for gfx950: C[M,N] = opA(A) . opB(B) (+ epilogue), fp32 accumulate.
+//
+// One kernel template serves the three contractions of every Linear in the denoiser:
+//   forward  Y  = X  . W^T          (transA=0, transB=0)   K-contiguous operands
+//   dgrad    dX = dY . W            (transA=0, transB=1)   W is [red][out]   -> transposed staging of B
+//   wgrad    dW = dY^T . X          (transA=1, transB=1)   both [red][out]   -> transposed staging of A and B
+// and both operand types: bf16 (v_mfma_f32_16x16x32_bf16) and exact fp32 (v_mfma_f32_16x16x4_f32, the
+// parity mode).  Reference op sequence replaced: nn.Linear fwd/bwd inside diffusers blocks
+// (reference src/duwu/modules/rope_unet.py:122-166, 404).
+//
+// Tiling: 128x128 output tile per 256-thread workgroup (4 waves, 2x2, 64x64 per wave = 4x4 MFMA 16x16 tiles),
+// K step = 128 bytes per row (64 bf16 / 32 fp32), LDS double-buffered (2 x 32 KB -> 2 workgroups per CU).
+// LDS image: [row][128 B], 16-B chunk c of row r stored at chunk (c ^ (r>>1) ^ (r>>4)) & 7:
+//   * fragment reads (ds_read_b128, lane -> row, fixed chunk) are bank-conflict free,
+//   * row-major staging writes (8 lanes x 16 B per row) are conflict free,
+//   * transposed staging writes (ds_write_b64 bf16 / ds_write_b128 fp32) are <= 2-way.
+// The fp32 path reuses the same image: lane group g=lane>>4 reads chunk 4*kk+g and feeds element e of it to
+// the e-th 16x16x4 MFMA, i.e. a k-permutation applied identically to A and B.
+// Global->LDS goes through registers (prefetch of tile t+1 issued before the MFMAs of tile t); K-strided
+// operands are transposed in registers (4x8 bf16 / 4x4 fp32 blocks) so HBM reads stay 16 B/lane coalesced.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128;
+constexpr int ROW_BYTES = 128;
+constexpr int TILE_BYTES = 128 * ROW_BYTES;  // 16 KB per operand tile
+
+template <typename T> struct GT;
+template <> struct GT<bf16_t> { static constexpr int EPC = 8; static constexpr int BK = 64; };
+template <> struct GT<float> { static constexpr int EPC = 4; static constexpr int BK = 32; };
+
+__device__ __forceinline__ int swz(int row, int chunk) {
+  return row * ROW_BYTES + (((chunk ^ (row >> 1) ^ (row >> 4)) & 7) << 4);
+}
+
+// ---- staging: one 128-row x 128-byte operand tile per call, 256 threads ------------------------------
+template <typename T, bool TRANS>
+struct Stager {
+  uint4 r[4];
+
+  // base: operand base pointer; ld: leading dimension (elements); row0: first output-row (m or n) of the tile;
+  // k0: first reduction index; nrows: operand extent in the output dim; K: reduction extent.
+  __device__ __forceinline__ void load(const T* __restrict__ base, int ld, int row0, int k0, int nrows, int K,
+                                       int tid) {
+    constexpr int EPC = GT<T>::EPC;
+    if constexpr (!TRANS) {
+      const int c = tid & 7, rr = tid >> 3;
+      const int kk = k0 + c * EPC;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int grow = row0 + rr + 32 * p;
+        if (grow < nrows && kk < K)
+          r[p] = *reinterpret_cast<const uint4*>(base + (int64_t)grow * ld + kk);
+        else
+          r[p] = uint4{0, 0, 0, 0};
+      }
+    } else if constexpr (sizeof(T) == 2) {
+      const int xg = tid & 15, kg = tid >> 4;
+      const int x = row0 + 8 * xg;
+#pragma unroll
+      for (int kr = 0; kr < 4; ++kr) {
+        const int k = k0 + 4 * kg + kr;
+        if (k < K && x < nrows)
+          r[kr] = *reinterpret_cast<const uint4*>(base + (int64_t)k * ld + x);
+        else
+          r[kr] = uint4{0, 0, 0, 0};
+      }
+    } else {
+      const int xg = tid & 31, kg = tid >> 5;
+      const int x = row0 + 4 * xg;
+#pragma unroll
+      for (int kr = 0; kr < 4; ++kr) {
+        const int k = k0 + 4 * kg + kr;
+        if (k < K && x < nrows)
+          r[kr] = *reinterpret_cast<const uint4*>(base + (int64_t)k * ld + x);
+        else
+          r[kr] = uint4{0, 0, 0, 0};
+      }
+    }
+  }
+
+  __device__ __forceinline__ void store(char* __restrict__ lds, int tid) const {
+    if constexpr (!TRANS) {
+      const int c = tid & 7, rr = tid >> 3;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) *reinterpret_cast<uint4*>(lds + swz(rr + 32 * p, c)) = r[p];
+    } else if constexpr (sizeof(T) == 2) {
+      const int xg = tid & 15, kg = tid >> 4;
+      const unsigned* w0 = reinterpret_cast<const unsigned*>(&r[0]);
+      const unsigned* w1 = reinterpret_cast<const unsigned*>(&r[1]);
+      const unsigned* w2 = reinterpret_cast<const unsigned*>(&r[2]);
+      const unsigned* w3 = reinterpret_cast<const unsigned*>(&r[3]);
+#pragma unroll
+      for (int xi = 0; xi < 8; ++xi) {
+        const int row = 8 * xg + xi;
+        const unsigned sel = (xi & 1) ? 0x07060302u : 0x05040100u;
+        uint2 o;
+        o.x = __builtin_amdgcn_perm(w1[xi >> 1], w0[xi >> 1], sel);  // {k+1, k}
+        o.y = __builtin_amdgcn_perm(w3[xi >> 1], w2[xi >> 1], sel);  // {k+3, k+2}
+        *reinterpret_cast<uint2*>(lds + swz(row, kg >> 1) + 8 * (kg & 1)) = o;
+      }
+    } else {
+      const int xg = tid & 31, kg = tid >> 5;
+      const unsigned* w0 = reinterpret_cast<const unsigned*>(&r[0]);
+      const unsigned* w1 = reinterpret_cast<const unsigned*>(&r[1]);
+      const unsigned* w2 = reinterpret_cast<const unsigned*>(&r[2]);
+      const unsigned* w3 = reinterpret_cast<const unsigned*>(&r[3]);
+#pragma unroll
+      for (int xi = 0; xi < 4; ++xi) {
+        const int row = 4 * xg + xi;
+        *reinterpret_cast<uint4*>(lds + swz(row, kg)) = uint4{w0[xi], w1[xi], w2[xi], w3[xi]};
+      }
+    }
+  }
+};
+
+template <typename T>
+__device__ __forceinline__ void mma_frag(const uint4& a, const uint4& b, f32x4& c) {
+  if constexpr (sizeof(T) == 2) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a),
+                                                *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
+  } else {
+    const float* af = reinterpret_cast<const float*>(&a);
+    const float* bf = reinterpret_cast<const float*>(&b);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[e], c, 0, 0, 0);
+  }
+}
+
+struct GemmArgs {
+  const void* A;
+  const void* B;
+  void* C;
+  void* C2;
+  const float* bias;
+  const void* aux;
+  int M, N, K, lda, ldb, ldc, ldaux, epi, tiles_m, tiles_n, k_tiles_per_split;
+};
+
+// ACC = atomic-accumulate epilogue (standard accumulator orientation: registers walk rows, lanes walk
+// 16 consecutive columns -> 64-B atomic segments).  Otherwise the MFMA operands are swapped so that each lane
+// owns 4 consecutive columns of one row and can apply the epilogue on / store 8-16 B vectors directly.
+template <typename T, typename TC, bool TA, bool TB, bool ACC>
+__global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BK = GT<T>::BK;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give every XCD a
+  // contiguous run of tile ids (n fastest) -> the n-tiles of one A row-panel hit the same L2.
+  const int nblk = g.tiles_m * g.tiles_n;
+  int tile;
+  {
+    const int bid = blockIdx.x, xcd = bid & 7, loc = bid >> 3;
+    const int q = nblk >> 3, rm = nblk & 7;
+    tile = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + loc;
+  }
+  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int ktiles = (g.K + BK - 1) / BK;
+  const int kt_begin = blockIdx.z * g.k_tiles_per_split;
+  int kt_end = kt_begin + g.k_tiles_per_split;
+  if (kt_end > ktiles) kt_end = ktiles;
+  if (kt_begin >= kt_end) return;  // uniform per block
+
+  const T* A = static_cast<const T*>(g.A);
+  const T* B = static_cast<const T*>(g.B);
+
+  Stager<T, TA> sa;
+  Stager<T, TB> sb;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  sa.load(A, g.lda, m0, kt_begin * BK, g.M, g.K, tid);
+  sb.load(B, g.ldb, n0, kt_begin * BK, g.N, g.K, tid);
+  sa.store(smem, tid);
+  sb.store(smem + TILE_BYTES, tid);
+  __syncthreads();
+
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int cur = (kt - kt_begin) & 1;
+    const char* la = smem + cur * 2 * TILE_BYTES;
+    const char* lb = la + TILE_BYTES;
+    const bool more = (kt + 1 < kt_end);
+    if (more) {  // prefetch next tile into registers; latency hides under the MFMAs below
+      sa.load(A, g.lda, m0, (kt + 1) * BK, g.M, g.K, tid);
+      sb.load(B, g.ldb, n0, (kt + 1) * BK, g.N, g.K, tid);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      uint4 af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        af[i] = *reinterpret_cast<const uint4*>(la + swz(wm * 64 + 16 * i + fr, 4 * kk + fq));
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        bf[j] = *reinterpret_cast<const uint4*>(lb + swz(wn * 64 + 16 * j + fr, 4 * kk + fq));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if constexpr (ACC)
+            mma_frag<T>(af[i], bf[j], acc[i][j]);
+          else
+            mma_frag<T>(bf[j], af[i], acc[i][j]);
+        }
+    }
+    if (more) {
+      char* na = smem + (cur ^ 1) * 2 * TILE_BYTES;
+      sa.store(na, tid);
+      sb.store(na + TILE_BYTES, tid);
+    }
+    __syncthreads();
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  if constexpr (ACC) {
+    float* C = static_cast<float*>(g.C);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + 16 * j + fr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + wm * 64 + 16 * i + 4 * fq + r;
+          if (m < g.M && n < g.N) atomicAdd(C + (int64_t)m * g.ldc + n, acc[i][j][r]);
+        }
+      }
+  } else {
+    TC* C = static_cast<TC*>(g.C);
+    TC* C2 = static_cast<TC*>(g.C2);
+    const T* aux = static_cast<const T*>(g.aux);
+    const int epi = g.epi;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 64 + 16 * i + fr;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + 16 * j + 4 * fq;
+        if (m >= g.M || n >= g.N) continue;
+        f32x4 v = acc[i][j];
+        if (epi == UWU_EPI_BIAS || epi == UWU_EPI_BIAS_GELU || epi == UWU_EPI_BIAS_SILU) {
+          f32x4 bv = load4(g.bias + n);
+          v = v + bv;
+        }
+        if (epi == UWU_EPI_DGELU) {
+          f32x4 u = load4(aux + (int64_t)m * g.ldaux + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= dgelu_tanh_f(u[e]);
+        }
+        store4(C + (int64_t)m * g.ldc + n, v);
+        if (epi == UWU_EPI_BIAS_GELU) {
+          f32x4 a2;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a2[e] = gelu_tanh_f(v[e]);
+          store4(C2 + (int64_t)m * g.ldc + n, a2);
+        } else if (epi == UWU_EPI_BIAS_SILU) {
+          f32x4 a2;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a2[e] = silu_f(v[e]);
+          store4(C2 + (int64_t)m * g.ldc + n, a2);
+        }
+      }
+    }
+  }
+}
+
+template <typename T, typename TC, bool TA, bool TB, bool ACC>
+int launch(const GemmArgs& g, int split, hipStream_t st) {
+  auto kern = gemm_kernel<T, TC, TA, TB, ACC>;
+  static bool attr_done = false;  // per instantiation
+  if (!attr_done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        4 * TILE_BYTES);
+    attr_done = true;
+  }
+  dim3 grid(g.tiles_m * g.tiles_n, 1, split);
+  hipLaunchKernelGGL(kern, grid, dim3(256), 4 * TILE_BYTES, st, g);
+  UWU_LAUNCH_CHECK("gemm");
+  return UWU_OK;
+}
+
+template <typename T, typename TC>
+int dispatch_trans(const GemmArgs& g, int ta, int tb, bool acc, int split, hipStream_t st) {
+  if (acc) {
+    if constexpr (sizeof(TC) == 4) {
+      if (ta == 1 && tb == 1) return launch<T, float, true, true, true>(g, split, st);
+      if (ta == 0 && tb == 0) return launch<T, float, false, false, true>(g, split, st);
+      if (ta == 0 && tb == 1) return launch<T, float, false, true, true>(g, split, st);
+    }
+    uwu_set_error("gemm: ACCUM epilogue needs fp32 C and (transA,transB) in {(0,0),(0,1),(1,1)}");
+    return UWU_EINVAL;
+  }
+  if (ta == 0 && tb == 0) return launch<T, TC, false, false, false>(g, split, st);
+  if (ta == 0 && tb == 1) return launch<T, TC, false, true, false>(g, split, st);
+  if (ta == 1 && tb == 1) return launch<T, TC, true, true, false>(g, split, st);
+  uwu_set_error("gemm: (transA=1, transB=0) is not instantiated");
+  return UWU_EINVAL;
+}
+
+}  // namespace
+
+extern "C" int uwu_gemm(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux, int M,
+                        int N, int K, int lda, int ldb, int ldc, int ldaux, int transA, int transB, int dtype,
+                        int c_dtype, int epilogue, int split_k, void* stream) {
+  UWU_CHECK_ARG(A && B && C, "gemm: null operand");
+  UWU_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
+  UWU_CHECK_ARG(dtype == UWU_F32 || dtype == UWU_BF16, "gemm: bad dtype %d", dtype);
+  UWU_CHECK_ARG(c_dtype == UWU_F32 || c_dtype == dtype, "gemm: c_dtype must be fp32 or the operand dtype");
+  const int epc = dtype == UWU_BF16 ? 8 : 4;
+  const int bk = dtype == UWU_BF16 ? 64 : 32;
+  // 16-byte vector access rules (checked on the host so a bad shape can never fault on the device)
+  UWU_CHECK_ARG((((uintptr_t)A | (uintptr_t)B) & 15) == 0, "gemm: A/B must be 16-byte aligned");
+  UWU_CHECK_ARG(lda % epc == 0 && ldb % epc == 0, "gemm: lda/ldb must be multiples of %d", epc);
+  UWU_CHECK_ARG(transA ? (M % epc == 0) : (K % epc == 0), "gemm: A contiguous extent must be a multiple of %d", epc);
+  UWU_CHECK_ARG(transB ? (N % epc == 0) : (K % epc == 0), "gemm: B contiguous extent must be a multiple of %d", epc);
+  UWU_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? N : K), "gemm: leading dimension too small");
+  UWU_CHECK_ARG(epilogue >= UWU_EPI_NONE && epilogue <= UWU_EPI_ACCUM, "gemm: bad epilogue %d", epilogue);
+  const bool acc = epilogue == UWU_EPI_ACCUM;
+  if (!acc) {
+    UWU_CHECK_ARG(split_k <= 1, "gemm: split_k needs UWU_EPI_ACCUM");
+    UWU_CHECK_ARG(N % 4 == 0 && ldc % 4 == 0 && ldc >= N, "gemm: N and ldc must be multiples of 4");
+    const int cal = c_dtype == UWU_BF16 ? 7 : 15;
+    UWU_CHECK_ARG(((uintptr_t)C & cal) == 0, "gemm: C misaligned");
+    if (epilogue == UWU_EPI_BIAS || epilogue == UWU_EPI_BIAS_GELU || epilogue == UWU_EPI_BIAS_SILU)
+      UWU_CHECK_ARG(bias && ((uintptr_t)bias & 15) == 0, "gemm: bias missing/misaligned");
+    if (epilogue == UWU_EPI_BIAS_GELU || epilogue == UWU_EPI_BIAS_SILU)
+      UWU_CHECK_ARG(C2 && ((uintptr_t)C2 & cal) == 0, "gemm: C2 missing/misaligned");
+    if (epilogue == UWU_EPI_DGELU)
+      UWU_CHECK_ARG(aux && ldaux % 4 == 0 && ldaux >= N && ((uintptr_t)aux & (dtype == UWU_BF16 ? 7 : 15)) == 0,
+                    "gemm: aux missing/misaligned");
+  } else {
+    UWU_CHECK_ARG(c_dtype == UWU_F32 && ldc >= N, "gemm: ACCUM needs fp32 C");
+  }
+  GemmArgs g;
+  g.A = A; g.B = B; g.C = C; g.C2 = C2; g.bias = bias; g.aux = aux;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux; g.epi = epilogue;
+  g.tiles_m = (M + BM - 1) / BM;
+  g.tiles_n = (N + BN - 1) / BN;
+  const int ktiles = (K + bk - 1) / bk;
+  int split = split_k < 1 ? 1 : split_k;
+  if (split > ktiles) split = ktiles;
+  g.k_tiles_per_split = (ktiles + split - 1) / split;
+  split = (ktiles + g.k_tiles_per_split - 1) / g.k_tiles_per_split;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == UWU_BF16) {
+    if (c_dtype == UWU_BF16) return dispatch_trans<bf16_t, bf16_t>(g, transA, transB, acc, split, st);
+    return dispatch_trans<bf16_t, float>(g, transA, transB, acc, split, st);
+  }
+  return dispatch_trans<float, float>(g, transA, transB, acc, split, st);
+}

@@ -1,0 +1,275 @@
+// Objective kernels: schedule gather, RF time sampling, q-sample, fused loss fwd+bwd.
+// HBM-bound elementwise + wavefront-shuffle reductions.  Reference: src/duwu/loss/diffusion.py,
+// src/duwu/loss/rectified_flow.py (line cites at each kernel).
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------
+// diffusion.py:53-62 (sigma lookup), :141-153 (min-SNR), :155-167 (debias)
+__global__ void schedule_gather_kernel(const int64_t* __restrict__ t, const float* __restrict__ sigmas_desc,
+                                       const float* __restrict__ all_snr, const float* __restrict__ abar,
+                                       int n_train, int B, int snr_mode, float gamma, int debias,
+                                       float* __restrict__ coef) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int64_t ti = t[b];
+  ti = ti < 0 ? 0 : (ti >= n_train ? n_train - 1 : ti);
+  // position of t in the descending scheduler.timesteps is N-1-t
+  float sigma = sigmas_desc[n_train - 1 - ti];
+  float w = 1.f;
+  float snr = all_snr[ti];
+  if (snr_mode != 0) {
+    float m = fminf(snr, gamma);
+    w *= (snr_mode == 2) ? m / (snr + 1.f) : m / snr;
+  }
+  if (debias) {
+    float s = fminf(snr, 1000.f);
+    w *= 1.f / sqrtf(s);
+  }
+  float a = abar[ti];
+  coef[4 * b + 0] = sigma;
+  coef[4 * b + 1] = w;
+  coef[4 * b + 2] = sqrtf(a);
+  coef[4 * b + 3] = sqrtf(1.f - a);
+}
+
+// rectified_flow.py:29-42 and :98-129
+__global__ void rf_time_kernel(const float* __restrict__ u01, float smax, const float* __restrict__ tbl,
+                               int n, int B, float* __restrict__ coef, float* __restrict__ tout) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float max_time = smax / (1.f + smax);
+  float time = u01[b] * max_time;
+  float sigma = time / (1.f - time);
+  float ls = logf(fmaxf(sigma, 1e-10f));
+  // low_idx = argmax(cumsum(ls >= tbl)) = (#entries with tbl <= ls) - 1 for an ascending table,
+  // (0 when none), clamped to n-2.  Table is ascending so count by binary search.
+  int lo = 0, hi = n;  // first index with tbl[idx] > ls
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (tbl[mid] <= ls) lo = mid + 1; else hi = mid;
+  }
+  int low_idx = lo - 1;
+  if (low_idx < 0) low_idx = 0;
+  if (low_idx > n - 2) low_idx = n - 2;
+  int high_idx = low_idx + 1;
+  float low = tbl[low_idx], high = tbl[high_idx];
+  float w = (low - ls) / (low - high);
+  w = fminf(fmaxf(w, 0.f), 1.f);
+  tout[b] = (1.f - w) * (float)low_idx + w * (float)high_idx;
+  coef[4 * b + 0] = sigma;
+  coef[4 * b + 1] = 1.f;
+  coef[4 * b + 2] = 0.f;
+  coef[4 * b + 3] = 0.f;
+}
+
+// diffusion.py:77-82 ; rectified_flow.py:67-71
+__global__ void qsample_kernel(const float* __restrict__ x, const float* __restrict__ noise,
+                               const float* __restrict__ coef, int64_t n4, int64_t total4,
+                               float* __restrict__ noisy, bf16_t* __restrict__ noisy_bf) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < total4; i += stride) {
+    int b = (int)(i / n4);
+    float sigma = coef[4 * b];
+    float scale = 1.f / sqrtf(sigma * sigma + 1.f);
+    f32x4 xv = load4(x + 4 * i), nv = load4(noise + 4 * i), o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (xv[j] + nv[j] * sigma) * scale;
+    store4(noisy + 4 * i, o);
+    if (noisy_bf) store4(noisy_bf + 4 * i, o);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// diffusion.py:100-125 elementwise, in the reference's own operation order
+__device__ __forceinline__ void x0_eps(int ptype, float xt, float out, float s, float scales, float& x0,
+                                       float& eps) {
+  switch (ptype) {
+    case UWU_PT_SAMPLE:
+      x0 = out;
+      eps = (xt / scales - x0) / s;
+      break;
+    case UWU_PT_EPSILON:
+      eps = out;
+      x0 = xt / scales - s * eps;
+      break;
+    case UWU_PT_V:
+      x0 = scales * (xt - s * out);
+      eps = (xt / scales - x0) / s;
+      break;
+    default:  // UWU_PT_RF
+      x0 = (xt / scales - s * out) / (1.f + s);
+      eps = (xt / scales + out) / (1.f + s);
+      break;
+  }
+}
+// diffusion.py:84-98
+__device__ __forceinline__ float target_of(int ttype, float x0, float eps, float sa, float sb) {
+  switch (ttype) {
+    case UWU_PT_EPSILON: return eps;
+    case UWU_PT_V: return sa * eps - sb * x0;
+    case UWU_PT_SAMPLE: return x0;
+    default: return eps - x0;
+  }
+}
+// d pred / d model_output (per-sample scalar; every conversion is affine in `out`)
+__device__ __forceinline__ float pred_coeff(int ptype, int ttype, bool convert, float s, float scales,
+                                            float sa, float sb) {
+  if (!convert) return 1.f;
+  float dx0, deps;
+  switch (ptype) {
+    case UWU_PT_SAMPLE: dx0 = 1.f; deps = -1.f / s; break;
+    case UWU_PT_EPSILON: dx0 = -s; deps = 1.f; break;
+    case UWU_PT_V: dx0 = -scales * s; deps = scales; break;
+    default: dx0 = -s / (1.f + s); deps = 1.f / (1.f + s); break;
+  }
+  switch (ttype) {
+    case UWU_PT_EPSILON: return deps;
+    case UWU_PT_V: return sa * deps - sb * dx0;
+    case UWU_PT_SAMPLE: return dx0;
+    default: return deps - dx0;
+  }
+}
+
+// One workgroup per sample: pass over the sample computes pred/target, the squared-error sum
+// (wave shuffle + LDS reduce) and writes d loss / d out in the same pass -- the gradient only
+// needs per-sample scalars known up front (w_b, c_b, 1/(n*B)).  diffusion.py:177-193.
+template <typename TO, int NT>
+__global__ void __launch_bounds__(NT) loss_fwd_bwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ noise, const float* __restrict__ xt,
+    const TO* __restrict__ mo, const float* __restrict__ coef, int ptype, int ttype, int convert, int B,
+    int64_t n, float* __restrict__ losses, TO* __restrict__ grad, float* __restrict__ pred_o,
+    float* __restrict__ target_o) {
+  __shared__ float red[NT / 64];
+  const int b = blockIdx.x;
+  const float sigma = coef[4 * b], w = coef[4 * b + 1], sa = coef[4 * b + 2], sb = coef[4 * b + 3];
+  const float scales = 1.f / sqrtf(sigma * sigma + 1.f);
+  const float c = pred_coeff(ptype, ttype, convert != 0, sigma, scales, sa, sb);
+  const float gs = 2.f * w * c / ((float)n * (float)B);
+  const int64_t base = (int64_t)b * n;
+  float acc = 0.f;
+  for (int64_t i = (int64_t)threadIdx.x * 4; i < n; i += (int64_t)NT * 4) {
+    f32x4 xv = load4(x + base + i), nv = load4(noise + base + i), ov = load4(mo + base + i);
+    f32x4 xtv = convert ? load4(xt + base + i) : xv;
+    f32x4 pv, tv, gv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float p;
+      if (convert) {
+        float x0, eps;
+        x0_eps(ptype, xtv[j], ov[j], sigma, scales, x0, eps);
+        p = target_of(ttype, x0, eps, sa, sb);
+      } else {
+        p = ov[j];
+      }
+      float t = target_of(ttype, xv[j], nv[j], sa, sb);
+      float d = p - t;
+      acc += d * d;
+      pv[j] = p;
+      tv[j] = t;
+      gv[j] = gs * d;
+    }
+    store4(grad + base + i, gv);
+    if (pred_o) store4(pred_o + base + i, pv);
+    if (target_o) store4(target_o + base + i, tv);
+  }
+  float tot = block_sum<NT / 64>(acc, red);
+  if (threadIdx.x == 0) losses[b] = w * (tot / (float)n);
+}
+
+__global__ void mean_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) a += v[i];
+  float t = block_sum<4>(a, red);
+  if (threadIdx.x == 0) out[0] = t / (float)n;
+}
+
+template <typename T>
+__global__ void scale_inplace_kernel(T* __restrict__ y, int64_t n4, const float* __restrict__ scale) {
+  const float s = scale[0];
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n4; i += stride) {
+    f32x4 v = load4(y + 4 * i);
+    v = v * s;
+    store4(y + 4 * i, v);
+  }
+}
+
+// ------------------------------------------------------------------------------- C ABI
+
+extern "C" int uwu_schedule_gather(const int64_t* timesteps, const float* sigmas_desc, const float* all_snr,
+                                   const float* alphas_cumprod, int n_train, int B, int snr_mode, float gamma,
+                                   int debias, float* coef, void* stream) {
+  UWU_CHECK_ARG(timesteps && sigmas_desc && all_snr && alphas_cumprod && coef, "schedule_gather: null pointer");
+  UWU_CHECK_ARG(B > 0 && n_train > 1, "schedule_gather: B=%d n_train=%d", B, n_train);
+  UWU_CHECK_ARG(snr_mode >= 0 && snr_mode <= 2, "schedule_gather: snr_mode=%d", snr_mode);
+  hipLaunchKernelGGL(schedule_gather_kernel, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, timesteps,
+                     sigmas_desc, all_snr, alphas_cumprod, n_train, B, snr_mode, gamma, debias, coef);
+  UWU_LAUNCH_CHECK("schedule_gather");
+  return UWU_OK;
+}
+
+extern "C" int uwu_rf_time_to_sigma(const float* u01, float sigma_max, const float* log_sigmas_asc, int n_train,
+                                    int B, float* coef, float* timesteps, void* stream) {
+  UWU_CHECK_ARG(u01 && log_sigmas_asc && coef && timesteps, "rf_time_to_sigma: null pointer");
+  UWU_CHECK_ARG(B > 0 && n_train > 2, "rf_time_to_sigma: B=%d n_train=%d", B, n_train);
+  hipLaunchKernelGGL(rf_time_kernel, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, u01, sigma_max,
+                     log_sigmas_asc, n_train, B, coef, timesteps);
+  UWU_LAUNCH_CHECK("rf_time_to_sigma");
+  return UWU_OK;
+}
+
+extern "C" int uwu_qsample(const float* x, const float* noise, const float* coef, int B, int64_t n, float* noisy,
+                           void* noisy_bf16, void* stream) {
+  UWU_CHECK_ARG(x && noise && coef && noisy, "qsample: null pointer");
+  UWU_CHECK_ARG(B > 0 && n > 0 && n % 4 == 0, "qsample: n=%lld must be a positive multiple of 4", (long long)n);
+  int64_t total4 = (int64_t)B * n / 4;
+  hipLaunchKernelGGL(qsample_kernel, dim3(ew_grid(total4, 256)), dim3(256), 0, (hipStream_t)stream, x, noise, coef,
+                     n / 4, total4, noisy, (bf16_t*)noisy_bf16);
+  UWU_LAUNCH_CHECK("qsample");
+  return UWU_OK;
+}
+
+extern "C" int uwu_loss_fwd_bwd(const float* x, const float* noise, const float* xt, const void* model_output,
+                                int out_dtype, const float* coef, int pred_type, int target_type, int force_convert,
+                                int B, int64_t n, float* losses, float* loss_mean, void* grad_out, float* pred,
+                                float* target, void* stream) {
+  UWU_CHECK_ARG(x && noise && model_output && coef && losses && grad_out, "loss_fwd_bwd: null pointer");
+  UWU_CHECK_ARG(B > 0 && n > 0 && n % 4 == 0, "loss_fwd_bwd: n=%lld must be a positive multiple of 4", (long long)n);
+  UWU_CHECK_ARG(pred_type >= 0 && pred_type <= 3 && target_type >= 0 && target_type <= 3,
+                "loss_fwd_bwd: Unsupported prediction/target type %d/%d", pred_type, target_type);
+  int convert = (force_convert || pred_type != target_type) ? 1 : 0;
+  UWU_CHECK_ARG(!convert || xt, "loss_fwd_bwd: xt required when prediction_type != target_type");
+  constexpr int NT = 256;
+  if (out_dtype == UWU_F32) {
+    hipLaunchKernelGGL((loss_fwd_bwd_kernel<float, NT>), dim3(B), dim3(NT), 0, (hipStream_t)stream, x, noise, xt,
+                       (const float*)model_output, coef, pred_type, target_type, convert, B, n, losses,
+                       (float*)grad_out, pred, target);
+  } else if (out_dtype == UWU_BF16) {
+    hipLaunchKernelGGL((loss_fwd_bwd_kernel<bf16_t, NT>), dim3(B), dim3(NT), 0, (hipStream_t)stream, x, noise, xt,
+                       (const bf16_t*)model_output, coef, pred_type, target_type, convert, B, n, losses,
+                       (bf16_t*)grad_out, pred, target);
+  } else {
+    UWU_CHECK_ARG(false, "loss_fwd_bwd: bad dtype %d", out_dtype);
+  }
+  UWU_LAUNCH_CHECK("loss_fwd_bwd");
+  if (loss_mean) {
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, losses, B, loss_mean);
+    UWU_LAUNCH_CHECK("loss_mean");
+  }
+  return UWU_OK;
+}
+
+extern "C" int uwu_scale_inplace(void* y, int dtype, int64_t n, const float* scale, void* stream) {
+  UWU_CHECK_ARG(y && scale && n > 0 && n % 4 == 0, "scale_inplace: bad args (n=%lld)", (long long)n);
+  if (dtype == UWU_F32)
+    hipLaunchKernelGGL((scale_inplace_kernel<float>), dim3(ew_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (float*)y, n / 4, scale);
+  else
+    hipLaunchKernelGGL((scale_inplace_kernel<bf16_t>), dim3(ew_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (bf16_t*)y, n / 4, scale);
+  UWU_LAUNCH_CHECK("scale_inplace");
+  return UWU_OK;
+}

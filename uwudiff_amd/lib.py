@@ -1,0 +1,126 @@
+"""ctypes binding of libuwu_hip.so (the C ABI declared in include/uwu_hip.h).
+
+The product path has NO fallback: if the library is missing or a call fails, this module raises.
+PyTorch is only the owner of device memory and streams -- every entry takes raw device pointers.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libuwu_hip.so")
+
+F32, BF16 = 0, 1
+PT = {"epsilon": 0, "v_prediction": 1, "sample": 2, "rectified_flow": 3}
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_DGELU, EPI_BIAS_SILU, EPI_ACCUM = 0, 1, 2, 3, 4, 5
+
+
+class UwuError(RuntimeError):
+    pass
+
+
+class DitDesc(ctypes.Structure):
+    _fields_ = (
+        [(n, c_int32) for n in ("B", "T", "D", "H", "L", "mlp_ratio", "in_ch", "out_ch", "patch", "img", "dtype",
+                                "cond_dim")]
+        + [("ln_eps", c_float), ("mod_total", c_int32)]
+        + [("w", c_void_p), ("w32", c_void_p), ("g32", c_void_p)]
+        + [(n, c_int64) for n in ("off_patch_w", "off_patch_b", "off_t_w1", "off_t_b1", "off_t_w2", "off_t_b2",
+                                  "off_y_w", "off_y_b", "off_mod_w", "off_mod_b", "off_final_w", "off_final_b",
+                                  "off_layer0", "layer_stride")]
+        + [("pos", c_void_p), ("ws", c_void_p), ("ws_bytes", c_size_t)]
+    )
+
+
+P = c_void_p
+_SIGS = {
+    "uwu_last_error": (c_char_p, []),
+    "uwu_version": (c_int, []),
+    "uwu_schedule_gather": (c_int, [P, P, P, P, c_int, c_int, c_int, c_float, c_int, P, P]),
+    "uwu_rf_time_to_sigma": (c_int, [P, c_float, P, c_int, c_int, P, P, P]),
+    "uwu_qsample": (c_int, [P, P, P, c_int, c_int64, P, P, P]),
+    "uwu_loss_fwd_bwd": (c_int, [P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int64, P, P, P, P, P, P]),
+    "uwu_scale_inplace": (c_int, [P, c_int, c_int64, P, P]),
+    "uwu_grad_sqnorm_clip": (c_int, [P, c_int64, c_float, c_float, P, P, P]),
+    "uwu_adamw_step": (c_int, [P, P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float,
+                               P, P]),
+    "uwu_cast_f32_to_bf16": (c_int, [P, P, c_int64, P]),
+    "uwu_cast_bf16_to_f32": (c_int, [P, P, c_int64, P]),
+    "uwu_gemm": (c_int, [P, P, P, P, P, P] + [c_int] * 14 + [P]),
+    "uwu_colsum": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, P]),
+    "uwu_add_ln_modulate_fwd": (c_int, [P, P, P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_float, c_int, P]),
+    "uwu_add_ln_modulate_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "uwu_attention_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "uwu_attention_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "uwu_timestep_embedding": (c_int, [P, c_int, c_int, c_float, P, c_int, P]),
+    "uwu_silu_fwd": (c_int, [P, P, c_int64, c_int, P]),
+    "uwu_silu_bwd": (c_int, [P, P, P, c_int64, c_int, P]),
+    "uwu_patchify": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "uwu_unpatchify": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "uwu_add_pos": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "uwu_dit_workspace_bytes": (c_size_t, [ctypes.POINTER(DitDesc)]),
+    "uwu_dit_forward": (c_int, [ctypes.POINTER(DitDesc), P, P, P, P, P]),
+    "uwu_dit_backward": (c_int, [ctypes.POINTER(DitDesc), P, P]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def load():
+    """Load libuwu_hip.so and declare every signature.  Raises if absent (no CPU fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise UwuError(
+            f"{LIB_PATH} not found: build it with `python -m uwudiff_amd.build` "
+            "(the HIP extension is required; there is no fallback path)"
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().uwu_last_error().decode(errors="replace")
+        raise UwuError(f"{what} failed (code {rc}): {msg}")
+
+
+def dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise UwuError(f"unsupported dtype {t.dtype}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Tensors must be contiguous CUDA(HIP) tensors."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise UwuError("libuwu_hip kernels need device tensors (got a CPU tensor); there is no CPU path")
+    if not t.is_contiguous():
+        raise UwuError("libuwu_hip kernels need contiguous tensors")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    check(rc, name)

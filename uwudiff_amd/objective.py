@@ -1,0 +1,241 @@
+"""Diffusion / rectified-flow objectives on the HIP kernels of csrc/objective.hip.
+
+Mirrors the reference operator interface (same names, arguments and error behaviour):
+  * ``DiffusionLoss``      -- reference src/duwu/loss/diffusion.py:18-193
+  * ``RectifiedFlowLoss``  -- reference src/duwu/loss/rectified_flow.py:9-129
+  * aux tuple              -- diffusion.py:9-15
+``forward(x, unet, **unet_kwargs) -> (scalar_loss, DiffusionLossAuxOutput)``.
+
+What changed underneath: the B host syncs per step of ``get_sigmas_for_timesteps`` (diffusion.py:58) and the
+Python ``torch.stack`` loops (:146,:159) are one ``uwu_schedule_gather`` launch; q-sample is one fused kernel;
+prediction conversion + target + per-sample MSE + SNR weights + d loss/d model_output are one fused kernel.
+"""
+from typing import Any, NamedTuple, Optional
+
+import torch
+import torch.nn as nn
+
+from . import lib as L
+from .scheduler import EulerDiscreteScheduler
+
+
+class DiffusionLossAuxOutput(NamedTuple):
+    losses: torch.Tensor
+    timesteps: torch.Tensor
+    pred: torch.Tensor
+    target: torch.Tensor
+    noisy_latent: torch.Tensor
+
+
+class _FusedLoss(torch.autograd.Function):
+    """loss = mean_b w_b * mean((pred-target)^2); the gradient wrt model_output is produced in the forward pass."""
+
+    @staticmethod
+    def forward(ctx, model_output, x, noise, xt, coef, pred_type, target_type, force_convert):
+        B = x.shape[0]
+        n = x[0].numel()
+        mo = model_output.contiguous()
+        if mo.dtype not in (torch.float32, torch.bfloat16):
+            mo = mo.float()
+        losses = torch.empty(B, device=x.device, dtype=torch.float32)
+        loss = torch.empty((), device=x.device, dtype=torch.float32)
+        grad = torch.empty_like(mo)
+        pred = torch.empty_like(x)
+        target = torch.empty_like(x)
+        L.call("uwu_loss_fwd_bwd", L.ptr(x), L.ptr(noise), L.ptr(xt), L.ptr(mo), L.dt(mo), L.ptr(coef),
+               pred_type, target_type, int(force_convert), B, n, L.ptr(losses), L.ptr(loss), L.ptr(grad),
+               L.ptr(pred), L.ptr(target), L.stream())
+        ctx.save_for_backward(grad)
+        ctx.out_dtype = model_output.dtype
+        ctx.mark_non_differentiable(losses, pred, target)
+        return loss, losses, pred, target
+
+    @staticmethod
+    def backward(ctx, g_loss, *_):
+        (grad,) = ctx.saved_tensors
+        g = g_loss.to(device=grad.device, dtype=torch.float32).contiguous()
+        L.call("uwu_scale_inplace", L.ptr(grad), L.dt(grad), grad.numel(), L.ptr(g), L.stream())
+        if grad.dtype != ctx.out_dtype:
+            grad = grad.to(ctx.out_dtype)
+        return grad, None, None, None, None, None, None, None
+
+
+class DiffusionLoss(nn.Module):
+    def __init__(
+        self,
+        scheduler: EulerDiscreteScheduler,
+        use_snr_weight: bool = False,
+        min_snr_gamma: float = 5.0,
+        use_debiased_estimation: bool = False,
+        prediction_type: Optional[str] = None,
+        target_type: Optional[str] = None,
+        loss: Optional[nn.Module] = None,
+    ):
+        super().__init__()
+        if loss is not None and not (isinstance(loss, nn.MSELoss) and loss.reduction == "none"):
+            raise NotImplementedError("only nn.MSELoss(reduction='none') is implemented on the HIP path")
+        self.scheduler = scheduler
+        self.prepare_scheduler_for_custom_training()
+        self.use_snr_weight = use_snr_weight
+        self.min_snr_gamma = min_snr_gamma
+        self.use_debiased_estimation = use_debiased_estimation
+        self.prediction_type = prediction_type or self.scheduler.config.prediction_type
+        self.target_type = target_type or self.scheduler.config.prediction_type
+        self.n_diffusion_time_steps = self.scheduler.config.num_train_timesteps
+        self._tables = {}
+        self._inject = None
+
+    # diffusion.py:42-51
+    def prepare_scheduler_for_custom_training(self):
+        if hasattr(self.scheduler, "all_snr"):
+            return
+        abar = self.scheduler.alphas_cumprod
+        self.scheduler.all_snr = (torch.sqrt(abar) / torch.sqrt(1.0 - abar)) ** 2
+
+    def inject(self, noise=None, timesteps=None, u01=None):
+        """One-shot RNG injection for parity runs (CPU and HIP generators differ)."""
+        self._inject = dict(noise=noise, timesteps=timesteps, u01=u01)
+
+    def _take_injected(self, key):
+        if self._inject is None:
+            return None
+        return self._inject.get(key)
+
+    def _dev_tables(self, device):
+        t = self._tables.get(device)
+        if t is None:
+            s = self.scheduler
+            t = dict(
+                sigmas=s.sigmas.to(device=device, dtype=torch.float32).contiguous(),
+                all_snr=s.all_snr.to(device=device, dtype=torch.float32).contiguous(),
+                abar=s.alphas_cumprod.to(device=device, dtype=torch.float32).contiguous(),
+                log_sigmas_asc=torch.log(s.sigmas[:-1]).flip(0).to(device=device, dtype=torch.float32).contiguous(),
+            )
+            self._tables[device] = t
+        return t
+
+    @staticmethod
+    def _type_id(name, what):
+        if name not in L.PT:
+            raise ValueError(f"Unsupported {what} type {name}")
+        return L.PT[name]
+
+    def _snr_mode(self):
+        if not self.use_snr_weight:
+            return 0
+        assert self.prediction_type == self.target_type
+        assert self.prediction_type in ["epsilon", "v_prediction"]
+        return 2 if self.prediction_type == "v_prediction" else 1
+
+    # diffusion.py:53-72
+    def sample_timesteps_and_sigmas(self, ref_params: torch.Tensor):
+        B = ref_params.size(0)
+        t = self._take_injected("timesteps")
+        if t is None:
+            t = torch.randint(0, self.scheduler.config.num_train_timesteps, (B,), device=ref_params.device)
+        t = t.to(device=ref_params.device, dtype=torch.int64).contiguous()
+        debias = 0
+        if self.use_debiased_estimation:
+            assert self.prediction_type == self.target_type == "epsilon"
+            debias = 1
+        tb = self._dev_tables(ref_params.device)
+        coef = torch.empty(B, 4, device=ref_params.device, dtype=torch.float32)
+        L.call("uwu_schedule_gather", L.ptr(t), L.ptr(tb["sigmas"]), L.ptr(tb["all_snr"]), L.ptr(tb["abar"]),
+               self.n_diffusion_time_steps, B, self._snr_mode(), float(self.min_snr_gamma), debias, L.ptr(coef),
+               L.stream())
+        return t, coef
+
+    def get_sigmas_for_timesteps(self, timesteps):
+        return self.scheduler.sigmas.to(timesteps.device)[self.n_diffusion_time_steps - 1 - timesteps.long()]
+
+    @staticmethod
+    def _qsample(x, noise, coef):
+        noisy = torch.empty_like(x)
+        L.call("uwu_qsample", L.ptr(x), L.ptr(noise), L.ptr(coef), x.shape[0], x[0].numel(), L.ptr(noisy), None,
+               L.stream())
+        return noisy
+
+    def _noise_like(self, x):
+        n = self._take_injected("noise")
+        if n is None:
+            return torch.randn_like(x)
+        return n.to(device=x.device, dtype=torch.float32).contiguous()
+
+    # diffusion.py:169-193
+    def forward(self, x: torch.Tensor, unet: nn.Module, **unet_kwargs):
+        pt = self._type_id(self.prediction_type, "prediction")
+        tt = self._type_id(self.target_type, "target")
+        x = x.float().contiguous()
+        noise = self._noise_like(x)  # drawn before the timesteps, as diffusion.py:75-76
+        timesteps, coef = self.sample_timesteps_and_sigmas(x)
+        self._inject = None
+        noisy = self._qsample(x, noise, coef)
+        model_output = unet(noisy, timesteps, **unet_kwargs)[0]
+        # NB the reference hands the *clean* x to get_prediction_for_training as `xt` (diffusion.py:177)
+        loss, losses, pred, target = _FusedLoss.apply(model_output, x, noise, x, coef, pt, tt, False)
+        aux = DiffusionLossAuxOutput(losses=losses, timesteps=timesteps, pred=pred, target=target,
+                                     noisy_latent=noisy)
+        return loss, aux
+
+
+class RectifiedFlowLoss(DiffusionLoss):
+    def __init__(
+        self,
+        time_sampling_type: str = "uniform_time",
+        time_sampling_kwargs: dict[str, Any] = {},
+        rescale_image: bool = False,
+        rescale_noise: bool = False,
+        **kwargs,
+    ):
+        super().__init__(**kwargs)
+        self.target_type = "rectified_flow"
+        self.time_sampling_type = time_sampling_type
+        self.time_sampling_kwargs = time_sampling_kwargs
+        self.rescale_image = rescale_image
+        self.rescale_noise = rescale_noise
+
+    # rectified_flow.py:26-47
+    def sample_timesteps_and_sigmas(self, ref_params: torch.Tensor):
+        if self.time_sampling_type == "uniform_timestep":
+            return super().sample_timesteps_and_sigmas(ref_params)
+        if self.time_sampling_type != "uniform_time":
+            raise ValueError(f"Unsupported time sampling type: {self.time_sampling_type}")
+        B = ref_params.size(0)
+        u = self._take_injected("u01")
+        if u is None:
+            u = torch.rand(B, device=ref_params.device)
+        u = u.to(device=ref_params.device, dtype=torch.float32).contiguous()
+        tb = self._dev_tables(ref_params.device)
+        coef = torch.empty(B, 4, device=ref_params.device, dtype=torch.float32)
+        timesteps = torch.empty(B, device=ref_params.device, dtype=torch.float32)
+        L.call("uwu_rf_time_to_sigma", L.ptr(u), float(self.scheduler.sigmas[0]), L.ptr(tb["log_sigmas_asc"]),
+               self.n_diffusion_time_steps, B, L.ptr(coef), L.ptr(timesteps), L.stream())
+        return timesteps, coef
+
+    # rectified_flow.py:49-61
+    def get_x0_and_noises(self, x: torch.Tensor):
+        if len(x.shape) == 5:
+            noises = x[:, 1, ...].float().contiguous()
+            x = x[:, 0, ...].float().contiguous()
+        else:
+            x = x.float().contiguous()
+            noises = self._noise_like(x)
+        if self.rescale_image:
+            x = (x / x.std([1, 2, 3], keepdim=True) * 0.937).contiguous()
+        if self.rescale_noise:
+            noises = (noises / noises.std([1, 2, 3], keepdim=True)).contiguous()
+        return x, noises
+
+    # rectified_flow.py:63-96
+    def forward(self, x: torch.Tensor, unet: nn.Module, **unet_kwargs):
+        pt = self._type_id(self.prediction_type, "prediction")
+        x, noises = self.get_x0_and_noises(x)
+        timesteps, coef = self.sample_timesteps_and_sigmas(x)
+        self._inject = None
+        noisy = self._qsample(x, noises, coef)
+        model_output = unet(noisy, timesteps, **unet_kwargs)[0]
+        loss, losses, pred, target = _FusedLoss.apply(model_output, x, noises, noisy, coef, pt, L.PT["rectified_flow"],
+                                                      True)
+        aux = DiffusionLossAuxOutput(losses=losses, timesteps=timesteps, pred=pred, target=target,
+                                     noisy_latent=noisy)
+        return loss, aux
