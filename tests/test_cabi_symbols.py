@@ -49,3 +49,16 @@ def test_product_does_not_import_oracle():
                     if re.search(r"^\s*(from|import)\s+oracle\b", s, flags=re.M):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_ctypes_arity_matches_header():
+    """Every ctypes signature has exactly as many parameters as the C prototype in include/uwu_hip.h."""
+    from uwudiff_amd import lib
+
+    src = open(os.path.join(ROOT, "include", "uwu_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = dict(re.findall(r"\b(uwu_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S))
+    for name, (_, args) in lib._SIGS.items():
+        params = protos[name].strip()
+        n = 0 if params in ("", "void") else params.count(",") + 1
+        assert n == len(args), f"{name}: header has {n} params, ctypes table has {len(args)}"

@@ -1,0 +1,119 @@
+"""GPU parity of the MFMA GEMM (C ABI uwu_gemm) vs a plain fp32 CPU matmul.
+
+Exact-integer operands make the bf16 and fp32 MFMA paths bit-checkable (products and sums are exactly
+representable), which catches any fragment-layout / swizzle / transpose error; random operands then check the
+tolerance: fp32 path 1e-5 rel (exact-fp32 MFMA), bf16 path compared against the same bf16-rounded operands.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(a, b, ta, tb):
+    A = a.float().cpu().double()
+    B = b.float().cpu().double()
+    A = A.t() if ta else A
+    B = B if tb else B.t()
+    return (A @ B).float()
+
+
+def _operands(M, N, K, ta, tb, dtype, ints, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    sa = (K, M) if ta else (M, K)
+    sb = (K, N) if tb else (N, K)
+    if ints:
+        a = torch.randint(-3, 4, sa, generator=g).float()
+        b = torch.randint(-3, 4, sb, generator=g).float()
+    else:
+        a = torch.randn(sa, generator=g)
+        b = torch.randn(sb, generator=g)
+    return a.to(dtype).cuda(), b.to(dtype).cuda()
+
+
+SHAPES = [(128, 128, 64), (256, 384, 384), (200, 72, 40), (16, 2304, 384), (1000, 16, 384), (512, 384, 16),
+          (130, 132, 200)]
+TRANS = [(False, False), (False, True), (True, True)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ta,tb", TRANS)
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_gemm_exact_integers(M, N, K, ta, tb, dtype):
+    from uwudiff_amd import ops
+
+    epc = 8 if dtype == torch.bfloat16 else 4
+    if (ta and M % epc) or (tb and N % epc) or ((not ta or not tb) and K % epc) or N % 4:
+        pytest.skip("shape violates the kernel's 16-byte vector rule for this layout (host check covers it)")
+    a, b = _operands(M, N, K, ta, tb, dtype, ints=True)
+    c = ops.gemm(a, b, trans_a=ta, trans_b=tb, c_dtype=torch.float32)
+    torch.testing.assert_close(c.cpu(), _ref(a, b, ta, tb), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ta,tb", TRANS)
+def test_gemm_random(ta, tb, dtype):
+    from uwudiff_amd import ops
+
+    M, N, K = 384, 256, 1536
+    a, b = _operands(M, N, K, ta, tb, dtype, ints=False, seed=1)
+    c = ops.gemm(a, b, trans_a=ta, trans_b=tb, c_dtype=torch.float32)
+    torch.testing.assert_close(c.cpu(), _ref(a, b, ta, tb), rtol=2e-5, atol=2e-4)
+    if dtype == torch.bfloat16:
+        cb = ops.gemm(a, b, trans_a=ta, trans_b=tb)
+        assert cb.dtype == torch.bfloat16
+        torch.testing.assert_close(cb.float().cpu(), _ref(a, b, ta, tb).bfloat16().float(), rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_epilogues(dtype):
+    import torch.nn.functional as F
+
+    from uwudiff_amd import lib as L
+    from uwudiff_amd import ops
+
+    M, N, K = 260, 384, 128
+    a, b = _operands(M, N, K, False, False, dtype, ints=False, seed=2)
+    bias = torch.randn(N).cuda()
+    ref = _ref(a, b, False, False) + bias.cpu()
+    tol = dict(rtol=1e-5, atol=1e-4) if dtype == torch.float32 else dict(rtol=2e-2, atol=3e-2)
+    c = ops.gemm(a, b, bias=bias, epilogue=L.EPI_BIAS)
+    torch.testing.assert_close(c.float().cpu(), ref, **tol)
+    u, f = ops.gemm(a, b, bias=bias, epilogue=L.EPI_BIAS_GELU)
+    torch.testing.assert_close(u.float().cpu(), ref, **tol)
+    torch.testing.assert_close(f.float().cpu(), F.gelu(u.float().cpu(), approximate="tanh"), **tol)
+    u, s = ops.gemm(a, b, bias=bias, epilogue=L.EPI_BIAS_SILU)
+    torch.testing.assert_close(s.float().cpu(), F.silu(u.float().cpu()), **tol)
+    # dgelu: C = (A.B) * gelu'(aux)
+    aux = torch.randn(M, N).to(dtype).cuda()
+    x = aux.float().cpu().requires_grad_(True)
+    F.gelu(x, approximate="tanh").sum().backward()
+    d = ops.gemm(a, b, aux=aux, epilogue=L.EPI_DGELU)
+    torch.testing.assert_close(d.float().cpu(), _ref(a, b, False, False) * x.grad, **tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("split", [1, 4, 7])
+def test_gemm_wgrad_accumulate(dtype, split):
+    """dW += dY^T X with split-K atomics; integer data keeps fp32 atomics order-independent (exact)."""
+    from uwudiff_amd import lib as L
+    from uwudiff_amd import ops
+
+    Mtok, Nout, Kin = 2048, 384, 136
+    g = torch.Generator().manual_seed(3)
+    dy = torch.randint(-2, 3, (Mtok, Nout), generator=g).float().to(dtype).cuda()
+    x = torch.randint(-2, 3, (Mtok, Kin), generator=g).float().to(dtype).cuda()
+    dw = torch.ones(Nout, Kin, device="cuda")
+    ops.gemm(dy, x, trans_a=True, trans_b=True, epilogue=L.EPI_ACCUM, out=dw, split_k=split)
+    ref = 1.0 + dy.float().cpu().t() @ x.float().cpu()
+    torch.testing.assert_close(dw.cpu(), ref, rtol=0, atol=0)
+
+
+def test_gemm_rejects_bad_shapes():
+    from uwudiff_amd import lib as L
+    from uwudiff_amd import ops
+
+    a = torch.zeros(128, 66, device="cuda", dtype=torch.bfloat16)  # K=66 not a multiple of 8
+    b = torch.zeros(128, 66, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(L.UwuError):
+        ops.gemm(a, b)

@@ -278,7 +278,7 @@ int launch(const GemmArgs& g, int split, hipStream_t st) {
   auto kern = gemm_kernel<T, TC, TA, TB, ACC>;
   static bool attr_done = false;  // per instantiation
   if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                         4 * TILE_BYTES);
     attr_done = true;
   }

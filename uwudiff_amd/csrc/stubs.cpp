@@ -5,7 +5,6 @@
 void uwu_set_error(const char* fmt, ...);
 #define STUB(name) { uwu_set_error(#name ": not implemented"); return UWU_ENOTIMPL; }
 extern "C" {
-int uwu_gemm(const void*, const void*, void*, void*, const float*, const void*, int, int, int, int, int, int, int, int, int, int, int, int, int, void*) STUB(uwu_gemm)
 int uwu_colsum(const void*, int, int, int, int, float*, int, void*) STUB(uwu_colsum)
 int uwu_add_ln_modulate_fwd(const void*, const void*, const float*, const float*, const float*, int, void*, void*, float*, float*, int, int, int, float, int, void*) STUB(uwu_add_ln_modulate_fwd)
 int uwu_add_ln_modulate_bwd(const void*, const void*, const float*, const float*, const float*, const void*, const void*, const float*, int, void*, void*, float*, float*, float*, int, int, int, int, void*) STUB(uwu_add_ln_modulate_bwd)
