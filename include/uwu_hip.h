@@ -144,14 +144,17 @@ int uwu_add_ln_modulate_bwd(const void* dh, const void* x, const float* mean, co
 
 /* ------------------------------------------------------------------ attention (a12) */
 
-/* softmax(Q K^T / sqrt(d)) V over packed qkv [B*T, 3*H*d] (q | k | v, heads contiguous inside each),
- * non-causal, no mask (rope_unet.py:151-153 F.scaled_dot_product_attention).  o: [B*T, H*d];
- * lse: fp32 [B,H,T] (log-sum-exp of scaled scores), saved for backward. */
-int uwu_attention_fwd(const void* qkv, void* o, float* lse, int B, int T, int H, int d, int dtype,
-                      void* stream);
-/* dqkv [B*T, 3*H*d] from (qkv, o, do, lse).  delta: fp32 workspace [B,H,T]. */
-int uwu_attention_bwd(const void* qkv, const void* o, const void* dO, const float* lse, float* delta,
-                      void* dqkv, int B, int T, int H, int d, int dtype, void* stream);
+/* o = softmax(scale * Q K^T) V, non-causal, no mask (rope_unet.py:151-153 F.scaled_dot_product_attention;
+ * diffusers AttnProcessor2_0 for the stock UNet).  Row (b,t) of q lives at q + (b*Tq+t)*ldq + h*d, likewise
+ * k/v with Tk, ldk/ldv and o with ldo -- so a packed [B*T, 3*H*d] projection is addressed in place with
+ * q=base, k=base+H*d, v=base+2*H*d, ld=3*H*d, and cross-attention (Tk=77) uses separate tensors.
+ * lse: fp32 [B,H,Tq] log-sum-exp of the scaled scores (saved for backward). */
+int uwu_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int Tq, int Tk,
+                      int H, int d, int ldq, int ldk, int ldv, int ldo, float scale, int dtype, void* stream);
+/* dq/dk/dv use the strides of q/k/v; dO uses ldo.  delta: fp32 workspace [B,H,Tq] (rowsum(dO*O)). */
+int uwu_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dO,
+                      const float* lse, float* delta, void* dq, void* dk, void* dv, int B, int Tq, int Tk, int H,
+                      int d, int ldq, int ldk, int ldv, int ldo, float scale, int dtype, void* stream);
 
 /* ------------------------------------------------------------------ embeddings / layout (a11, a13) */
 

@@ -1,0 +1,177 @@
+"""GPU parity of the non-GEMM denoiser kernels (C ABI) vs plain PyTorch fp32 CPU references + autograd.
+
+fp32 kernels: rtol 1e-4 (north-star bar is 1e-3).  bf16 kernels: compared at bf16 resolution (2e-2).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def tol(dtype):
+    return dict(rtol=1e-4, atol=1e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+
+
+def cmp(a, b, **kw):
+    torch.testing.assert_close(a.detach().float().cpu(), b.detach().float().cpu(), **kw)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("D", [384, 768, 1152, 64])
+def test_add_ln_modulate_fwd_bwd(D, dtype):
+    from uwudiff_amd import ops
+
+    torch.manual_seed(0)
+    B, T, ML = 3, 64, 6 * D + 8
+    x_in = torch.randn(B * T, D).to(dtype)
+    y = torch.randn(B * T, D).to(dtype)
+    mod = torch.randn(B, ML) * 0.5
+    dh = torch.randn(B * T, D).to(dtype)
+    dx_in = torch.randn(B * T, D).to(dtype)
+    # reference (fp32 math on the same rounded inputs)
+    xr, yr = x_in.float().requires_grad_(True), y.float().requires_grad_(True)
+    modr = mod.clone().requires_grad_(True)
+    gate, shift, scale = modr[:, 0:D], modr[:, D:2 * D], modr[:, 2 * D:3 * D]
+    xo = xr + gate.repeat_interleave(T, 0) * yr
+    if dtype == torch.bfloat16:
+        xo = xo + (xo.detach().bfloat16().float() - xo.detach())  # the kernel stores/normalises the rounded stream
+    hr = F.layer_norm(xo, (D,), eps=1e-6) * (1 + scale.repeat_interleave(T, 0)) + shift.repeat_interleave(T, 0)
+    (hr * dh.float()).sum().backward(retain_graph=True)
+    xo_grad_total = torch.autograd.grad((hr * dh.float()).sum(), xo, retain_graph=True)[0] + dx_in.float()
+
+    md = mod.cuda()
+    g, sh, sc = md[:, 0:D], md[:, D:2 * D], md[:, 2 * D:3 * D]
+    x_out, h, mean, rstd = ops.add_ln_modulate_fwd(x_in.cuda(), B, T, y=y.cuda(), gate=g, shift=sh, scale=sc, mod_ld=ML)
+    cmp(x_out, xo, **tol(dtype))
+    cmp(h, hr, **tol(dtype))
+    dmod = torch.zeros(B, ML, device="cuda")
+    dx, dy = ops.add_ln_modulate_bwd(dh.cuda(), x_out, mean, rstd, B, T, scale=sc, dx_in=dx_in.cuda(), y=y.cuda(),
+                                     gate=g, mod_ld=ML, dshift=dmod[:, D:2 * D], dscale=dmod[:, 2 * D:3 * D],
+                                     dgate=dmod[:, 0:D])
+    cmp(dx, xo_grad_total, **tol(dtype))
+    cmp(dy, gate.repeat_interleave(T, 0) * xo_grad_total, **tol(dtype))
+    # per-sample modulation grads: dgate uses the *total* residual gradient
+    dgate_ref = (xo_grad_total * y.float()).view(B, T, D).sum(1)
+    t2 = dict(rtol=1e-3, atol=1e-3) if dtype == torch.float32 else dict(rtol=3e-2, atol=0.3)
+    cmp(dmod[:, D:2 * D], modr.grad[:, D:2 * D], **t2)
+    cmp(dmod[:, 2 * D:3 * D], modr.grad[:, 2 * D:3 * D], **t2)
+    cmp(dmod[:, 0:D], dgate_ref, **t2)
+    assert dmod[:, 3 * D:].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_plain_ln_no_residual(dtype):
+    from uwudiff_amd import ops
+
+    torch.manual_seed(1)
+    B, T, D = 2, 32, 384
+    x = torch.randn(B * T, D).to(dtype)
+    _, h, mean, rstd = ops.add_ln_modulate_fwd(x.cuda(), B, T)
+    cmp(h, F.layer_norm(x.float(), (D,), eps=1e-6), **tol(dtype))
+    xr = x.float().requires_grad_(True)
+    dh = torch.randn(B * T, D).to(dtype)
+    (F.layer_norm(xr, (D,), eps=1e-6) * dh.float()).sum().backward()
+    dx, dy = ops.add_ln_modulate_bwd(dh.cuda(), x.cuda(), mean, rstd, B, T)
+    assert dy is None
+    cmp(dx, xr.grad, **tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,Tq,Tk,H,d,packed", [(2, 256, 256, 6, 64, True), (1, 64, 77, 2, 64, False),
+                                                 (2, 100, 40, 3, 72, False), (1, 128, 128, 2, 32, True)])
+def test_attention_fwd_bwd(B, Tq, Tk, H, d, packed, dtype):
+    from uwudiff_amd import ops
+
+    torch.manual_seed(0)
+    D = H * d
+    if packed:
+        qkv = torch.randn(B * Tq, 3 * D).to(dtype)
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+        qkv_d = qkv.cuda()
+        qd, kd, vd = qkv_d[:, :D], qkv_d[:, D:2 * D], qkv_d[:, 2 * D:]
+    else:
+        q, k, v = (torch.randn(B * Tq, D).to(dtype), torch.randn(B * Tk, D).to(dtype), torch.randn(B * Tk, D).to(dtype))
+        qd, kd, vd = q.cuda(), k.cuda(), v.cuda()
+    do = torch.randn(B * Tq, D).to(dtype)
+
+    def heads(t, T):
+        return t.float().reshape(B, T, H, d).transpose(1, 2)
+
+    qr, kr, vr = [heads(t, T).detach().requires_grad_(True) for t, T in ((q, Tq), (k, Tk), (v, Tk))]
+    orf = F.scaled_dot_product_attention(qr, kr, vr)
+    orf.backward(heads(do, Tq))
+    lse_ref = torch.logsumexp(qr.detach() @ kr.detach().transpose(-1, -2) / math.sqrt(d), dim=-1)
+
+    o, lse = ops.attention_fwd(qd, kd, vd, B, Tq, Tk, H, d)
+    cmp(o, orf.transpose(1, 2).reshape(B * Tq, D), **tol(dtype))
+    cmp(lse, lse_ref, rtol=1e-4, atol=1e-4 if dtype == torch.float32 else 3e-2)
+    if packed:
+        dqkv = torch.empty_like(qkv_d)
+        dq, dk, dv = dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:]
+    else:
+        dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    ops.attention_bwd(qd, kd, vd, o, do.cuda(), lse, dq, dk, dv, B, Tq, Tk, H, d)
+    t = tol(dtype) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+    cmp(dq, qr.grad.transpose(1, 2).reshape(B * Tq, D), **t)
+    cmp(dk, kr.grad.transpose(1, 2).reshape(B * Tk, D), **t)
+    cmp(dv, vr.grad.transpose(1, 2).reshape(B * Tk, D), **t)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_colsum(dtype):
+    from uwudiff_amd import ops
+
+    torch.manual_seed(0)
+    x = torch.randint(-4, 5, (1000, 72)).float().to(dtype)
+    out = ops.colsum(x.cuda())
+    cmp(out, x.float().sum(0), rtol=0, atol=0)
+    out = ops.colsum(x.cuda(), out=out, accumulate=True)
+    cmp(out, 2 * x.float().sum(0), rtol=0, atol=0)
+
+
+def test_embed_and_layout_kernels():
+    from uwudiff_amd import lib as L
+
+    torch.manual_seed(0)
+    B, dim = 5, 256
+    t = torch.tensor([0.0, 1.0, 250.5, 999.0, 37.0])
+    out = torch.empty(B, dim, device="cuda")
+    td = t.cuda()  # keep device temporaries alive: launches are asynchronous and take raw pointers
+    L.call("uwu_timestep_embedding", L.ptr(td), B, dim, 10000.0, L.ptr(out), L.F32, L.stream())
+    half = dim // 2
+    f = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    a = t[:, None] * f[None]
+    cmp(out, torch.cat([torch.cos(a), torch.sin(a)], -1), rtol=1e-4, atol=2e-4)
+    # silu fwd / bwd
+    x = torch.randn(1024)
+    y = torch.empty(1024, device="cuda")
+    xd_, ones = x.cuda(), torch.ones(1024, device="cuda")
+    L.call("uwu_silu_fwd", L.ptr(xd_), L.ptr(y), 1024, L.F32, L.stream())
+    cmp(y, F.silu(x), rtol=1e-5, atol=1e-6)
+    xr = x.clone().requires_grad_(True)
+    F.silu(xr).sum().backward()
+    dx = torch.empty(1024, device="cuda")
+    L.call("uwu_silu_bwd", L.ptr(xd_), L.ptr(ones), L.ptr(dx), 1024, L.F32, L.stream())
+    cmp(dx, xr.grad, rtol=1e-5, atol=1e-6)
+    # patchify == unfold of a stride-p conv; unpatchify inverts it
+    Bi, C, H, W, p = 2, 4, 8, 8, 2
+    img = torch.randn(Bi, C, H, W)
+    tok = torch.empty(Bi * (H // p) * (W // p), C * p * p, device="cuda")
+    imgd = img.cuda()
+    L.call("uwu_patchify", L.ptr(imgd), L.ptr(tok), Bi, C, H, W, p, L.F32, L.stream())
+    ref = F.unfold(img, kernel_size=p, stride=p).transpose(1, 2).reshape(-1, C * p * p)
+    cmp(tok, ref, rtol=0, atol=0)
+    back = torch.empty(Bi, C, H, W, device="cuda")
+    L.call("uwu_unpatchify", L.ptr(tok), L.F32, L.ptr(back), Bi, C, H, W, p, L.stream())
+    cmp(back, img, rtol=0, atol=0)
+    # add_pos
+    T_, D = 16, 8
+    xx = torch.randn(Bi * T_, D)
+    pos = torch.randn(T_, D)
+    xd = xx.cuda()
+    posd = pos.cuda()
+    L.call("uwu_add_pos", L.ptr(xd), L.ptr(posd), Bi, T_, D, L.F32, L.stream())
+    cmp(xd, xx + pos.repeat(Bi, 1), rtol=0, atol=1e-7)

@@ -1,0 +1,292 @@
+// adaLN-Zero pre-norm kernels (HBM-bound; one wavefront per token row, shuffle reductions).
+//   fwd:  x_out = x_in + gate_b*y ; h = LN(x_out)*(1+scale_b)+shift_b          (rope_unet.py:306-309,344-349,393-411)
+//   bwd:  dx_out = dx_in + LN_bwd(dh*(1+scale_b)) ; dy = gate_b*dx_out ; per-sample dshift/dscale/dgate
+// plus column sums for bias gradients.
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_D = 2048;  // NIT = ceil(D/256) <= 8 (template parameter: keeps the register arrays exact)
+
+template <typename T, int MAX_IT>
+__global__ void __launch_bounds__(256) add_ln_mod_fwd_kernel(const T* __restrict__ x_in, const T* __restrict__ y,
+                                                             const float* __restrict__ gate,
+                                                             const float* __restrict__ shift,
+                                                             const float* __restrict__ scale, int mod_ld,
+                                                             T* __restrict__ x_out, T* __restrict__ h,
+                                                             float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                             int M, int T_tok, int D, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nit = (D + 255) >> 8;
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const int b = row / T_tok;
+    const int64_t off = (int64_t)row * D;
+    f32x4 v[MAX_IT];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it) {
+      const int d = it * 256 + lane * 4;
+      if (it < nit && d < D) {
+        f32x4 xv = load4(x_in + off + d);
+        if (y) {
+          f32x4 yv = load4(y + off + d), gv = load4(gate + (int64_t)b * mod_ld + d);
+          xv = xv + gv * yv;
+          // keep the stored residual stream and the normalised value consistent in reduced precision
+          if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xv[e] = (float)(bf16_t)xv[e];
+          }
+          store4(x_out + off + d, xv);
+        }
+        v[it] = xv;
+        s += xv[0] + xv[1] + xv[2] + xv[3];
+      } else {
+        v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it) {
+      const int d = it * 256 + lane * 4;
+      if (it < nit && d < D) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float c = v[it][e] - mean;
+          q += c * c;
+        }
+      }
+    }
+    const float var = wave_sum(q) / (float)D;
+    const float rstd = 1.f / sqrtf(var + eps);
+    if (lane == 0) {
+      mean_o[row] = mean;
+      rstd_o[row] = rstd;
+    }
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it) {
+      const int d = it * 256 + lane * 4;
+      if (it < nit && d < D) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[it][e] - mean) * rstd;
+        if (scale) {
+          f32x4 sc = load4(scale + (int64_t)b * mod_ld + d), sh = load4(shift + (int64_t)b * mod_ld + d);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = o[e] * (1.f + sc[e]) + sh[e];
+        }
+        store4(h + off + d, o);
+      }
+    }
+  }
+}
+
+// One workgroup = ROWS consecutive rows of ONE sample (T_tok % ROWS == 0); the 4 waves split the rows, keep the
+// per-column partial sums for dshift/dscale/dgate in registers, fold them through LDS and issue one fp32 atomic
+// per column per workgroup.
+template <typename T, int MAX_IT>
+__global__ void __launch_bounds__(256) add_ln_mod_bwd_kernel(
+    const T* __restrict__ dh, const T* __restrict__ x, const float* __restrict__ mean_i,
+    const float* __restrict__ rstd_i, const float* __restrict__ scale, const T* __restrict__ dx_in,
+    const T* __restrict__ y, const float* __restrict__ gate, int mod_ld, T* __restrict__ dx_out, T* __restrict__ dy,
+    float* __restrict__ dshift, float* __restrict__ dscale, float* __restrict__ dgate, int M, int T_tok, int D,
+    int rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][3][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nit = (D + 255) >> 8;
+  const int row0 = blockIdx.x * rows_per_block;
+  const int b = row0 / T_tok;
+  f32x4 a_sh[MAX_IT], a_sc[MAX_IT], a_g[MAX_IT];
+#pragma unroll
+  for (int it = 0; it < MAX_IT; ++it) a_sh[it] = a_sc[it] = a_g[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int r = wave; r < rows_per_block; r += 4) {
+    const int row = row0 + r;
+    if (row >= M) break;
+    const int64_t off = (int64_t)row * D;
+    const float mean = mean_i[row], rstd = rstd_i[row];
+    f32x4 xh[MAX_IT], g[MAX_IT];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it) {
+      const int d = it * 256 + lane * 4;
+      if (it < nit && d < D) {
+        f32x4 xv = load4(x + off + d), dv = load4(dh + off + d);
+        f32x4 sc = scale ? load4(scale + (int64_t)b * mod_ld + d) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float xhat = (xv[e] - mean) * rstd;
+          float gg = dv[e] * (1.f + sc[e]);
+          xh[it][e] = xhat;
+          g[it][e] = gg;
+          s1 += gg;
+          s2 += gg * xhat;
+          a_sh[it][e] += dv[e];
+          a_sc[it][e] += dv[e] * xhat;
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it) {
+      const int d = it * 256 + lane * 4;
+      if (it < nit && d < D) {
+        f32x4 dx;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dx[e] = rstd * (g[it][e] - s1 - xh[it][e] * s2);
+        if (dx_in) dx = dx + load4(dx_in + off + d);
+        store4(dx_out + off + d, dx);
+        if (y) {
+          f32x4 yv = load4(y + off + d), gv = load4(gate + (int64_t)b * mod_ld + d);
+          store4(dy + off + d, gv * dx);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a_g[it][e] += dx[e] * yv[e];
+        }
+      }
+    }
+  }
+  // fold the 4 waves' column partials
+  float* mine = red + (int64_t)wave * 3 * D;
+#pragma unroll
+  for (int it = 0; it < MAX_IT; ++it) {
+    const int d = it * 256 + lane * 4;
+    if (it < nit && d < D) {
+      store4(mine + d, a_sh[it]);
+      store4(mine + D + d, a_sc[it]);
+      store4(mine + 2 * D + d, a_g[it]);
+    }
+  }
+  __syncthreads();
+  const int ncol = (y ? 3 : 2) * D;
+  for (int c = threadIdx.x; c < ncol; c += 256) {
+    float t = red[c] + red[3 * D + c] + red[6 * D + c] + red[9 * D + c];
+    const int which = c / D, d = c - which * D;
+    float* dst = which == 0 ? dshift : (which == 1 ? dscale : dgate);
+    if (dst) atomicAdd(dst + (int64_t)b * mod_ld + d, t);
+  }
+}
+
+// out[n] += sum_m X[m,n]: 16 row-lanes x 16 column-groups(4 cols) per workgroup, rows split over gridDim.y
+template <typename T>
+__global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ X, int M, int N, int ldx,
+                                                     float* __restrict__ out, int rows_per_block) {
+  __shared__ f32x4 red[16][17];
+  const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int n = blockIdx.x * 64 + cg * 4;
+  const int r0 = blockIdx.y * rows_per_block;
+  int r1 = r0 + rows_per_block;
+  if (r1 > M) r1 = M;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  if (n < N)
+    for (int r = r0 + rg; r < r1; r += 16) a = a + load4(X + (int64_t)r * ldx + n);
+  red[rg][cg] = a;
+  __syncthreads();
+  if (rg == 0 && n < N) {
+    f32x4 t = red[0][cg];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) t = t + red[i][cg];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(out + n + e, t[e]);
+  }
+}
+
+}  // namespace
+
+extern "C" int uwu_add_ln_modulate_fwd(const void* x_in, const void* y, const float* gate, const float* shift,
+                                       const float* scale, int mod_ld, void* x_out, void* h, float* mean, float* rstd,
+                                       int B, int T, int D, float eps, int dtype, void* stream) {
+  UWU_CHECK_ARG(x_in && h && mean && rstd, "add_ln_modulate_fwd: null pointer");
+  UWU_CHECK_ARG(B > 0 && T > 0 && D > 0 && D % 4 == 0 && D <= MAX_D, "add_ln_modulate_fwd: D=%d unsupported", D);
+  UWU_CHECK_ARG((y == nullptr) || (gate && x_out), "add_ln_modulate_fwd: y needs gate and x_out");
+  UWU_CHECK_ARG((scale == nullptr) == (shift == nullptr), "add_ln_modulate_fwd: scale/shift go together");
+  UWU_CHECK_ARG(!scale || mod_ld % 4 == 0, "add_ln_modulate_fwd: mod_ld must be a multiple of 4");
+  const int M = B * T;
+  int grid = (M + 3) / 4;
+  if (grid > 8192) grid = 8192;
+  hipStream_t st = (hipStream_t)stream;
+  UWU_CHECK_ARG(dtype == UWU_F32 || dtype == UWU_BF16, "add_ln_modulate_fwd: bad dtype");
+#define FWD_CASE(NIT)                                                                                              \
+  case NIT:                                                                                                        \
+    if (dtype == UWU_F32)                                                                                          \
+      hipLaunchKernelGGL((add_ln_mod_fwd_kernel<float, NIT>), dim3(grid), dim3(256), 0, st, (const float*)x_in,    \
+                         (const float*)y, gate, shift, scale, mod_ld, (float*)x_out, (float*)h, mean, rstd, M, T, D, \
+                         eps);                                                                                     \
+    else                                                                                                           \
+      hipLaunchKernelGGL((add_ln_mod_fwd_kernel<bf16_t, NIT>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x_in,  \
+                         (const bf16_t*)y, gate, shift, scale, mod_ld, (bf16_t*)x_out, (bf16_t*)h, mean, rstd, M,  \
+                         T, D, eps);                                                                               \
+    break;
+  switch ((D + 255) / 256) {
+    FWD_CASE(1) FWD_CASE(2) FWD_CASE(3) FWD_CASE(4) FWD_CASE(5) FWD_CASE(6) FWD_CASE(7) FWD_CASE(8)
+  }
+#undef FWD_CASE
+  UWU_LAUNCH_CHECK("add_ln_modulate_fwd");
+  return UWU_OK;
+}
+
+extern "C" int uwu_add_ln_modulate_bwd(const void* dh, const void* x, const float* mean, const float* rstd,
+                                       const float* scale, const void* dx_in, const void* y, const float* gate,
+                                       int mod_ld, void* dx_out, void* dy, float* dshift, float* dscale, float* dgate,
+                                       int B, int T, int D, int dtype, void* stream) {
+  UWU_CHECK_ARG(dh && x && mean && rstd && dx_out, "add_ln_modulate_bwd: null pointer");
+  UWU_CHECK_ARG(B > 0 && T > 0 && D > 0 && D % 4 == 0 && D <= MAX_D, "add_ln_modulate_bwd: D=%d unsupported", D);
+  UWU_CHECK_ARG((y == nullptr) || (gate && dy), "add_ln_modulate_bwd: y needs gate and dy");
+  UWU_CHECK_ARG(!(scale || y) || mod_ld % 4 == 0, "add_ln_modulate_bwd: mod_ld must be a multiple of 4");
+  int rows = 32;
+  while (rows > 1 && T % rows) rows >>= 1;
+  const int M = B * T;
+  const size_t lds = (size_t)4 * 3 * D * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  UWU_CHECK_ARG(dtype == UWU_F32 || dtype == UWU_BF16, "add_ln_modulate_bwd: bad dtype");
+  UWU_CHECK_ARG(lds <= 64 * 1024, "add_ln_modulate_bwd: D=%d needs %zu B of LDS (> 64 KB)", D, lds);
+#define BWD_CASE(NIT)                                                                                               \
+  case NIT:                                                                                                         \
+    if (dtype == UWU_F32)                                                                                           \
+      hipLaunchKernelGGL((add_ln_mod_bwd_kernel<float, NIT>), dim3(M / rows), dim3(256), lds, st, (const float*)dh, \
+                         (const float*)x, mean, rstd, scale, (const float*)dx_in, (const float*)y, gate, mod_ld,    \
+                         (float*)dx_out, (float*)dy, dshift, dscale, dgate, M, T, D, rows);                         \
+    else                                                                                                            \
+      hipLaunchKernelGGL((add_ln_mod_bwd_kernel<bf16_t, NIT>), dim3(M / rows), dim3(256), lds, st,                  \
+                         (const bf16_t*)dh, (const bf16_t*)x, mean, rstd, scale, (const bf16_t*)dx_in,              \
+                         (const bf16_t*)y, gate, mod_ld, (bf16_t*)dx_out, (bf16_t*)dy, dshift, dscale, dgate, M, T, \
+                         D, rows);                                                                                  \
+    break;
+  switch ((D + 255) / 256) {
+    BWD_CASE(1) BWD_CASE(2) BWD_CASE(3) BWD_CASE(4) BWD_CASE(5) BWD_CASE(6)
+    default:
+      UWU_CHECK_ARG(false, "add_ln_modulate_bwd: D=%d > 1536 not instantiated", D);
+  }
+#undef BWD_CASE
+  UWU_LAUNCH_CHECK("add_ln_modulate_bwd");
+  return UWU_OK;
+}
+
+extern "C" int uwu_colsum(const void* X, int dtype, int M, int N, int ldx, float* out, int accumulate, void* stream) {
+  UWU_CHECK_ARG(X && out && M > 0 && N > 0 && N % 4 == 0 && ldx % 4 == 0 && ldx >= N, "colsum: bad args (N=%d ldx=%d)", N,
+                ldx);
+  hipStream_t st = (hipStream_t)stream;
+  if (!accumulate) {
+    if (hipMemsetAsync(out, 0, (size_t)N * sizeof(float), st) != hipSuccess) {
+      uwu_set_error("colsum: memset failed");
+      return UWU_ELAUNCH;
+    }
+  }
+  int splits = (M + 255) / 256;
+  const int strips = (N + 63) / 64;
+  int want = 1024 / strips;
+  if (want < 1) want = 1;
+  if (splits > want) splits = want;
+  const int rows = (M + splits - 1) / splits;
+  splits = (M + rows - 1) / rows;
+  if (dtype == UWU_F32)
+    hipLaunchKernelGGL((colsum_kernel<float>), dim3(strips, splits), dim3(256), 0, st, (const float*)X, M, N, ldx, out,
+                       rows);
+  else if (dtype == UWU_BF16)
+    hipLaunchKernelGGL((colsum_kernel<bf16_t>), dim3(strips, splits), dim3(256), 0, st, (const bf16_t*)X, M, N, ldx,
+                       out, rows);
+  else
+    UWU_CHECK_ARG(false, "colsum: bad dtype");
+  UWU_LAUNCH_CHECK("colsum");
+  return UWU_OK;
+}

@@ -22,3 +22,60 @@ def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, aux=None, epilogue=L.
            b.stride(0), out.stride(0), aux.stride(0) if aux is not None else 0, int(trans_a), int(trans_b), L.dt(a),
            L.dt(out), epilogue, split_k, L.stream())
     return (out, out2) if out2 is not None else out
+
+
+def add_ln_modulate_fwd(x_in, B, T, *, y=None, gate=None, shift=None, scale=None, mod_ld=0, eps=1e-6):
+    M, D = x_in.shape
+    x_out = torch.empty_like(x_in) if y is not None else x_in
+    h = torch.empty_like(x_in)
+    mean = torch.empty(M, device=x_in.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    L.call("uwu_add_ln_modulate_fwd", L.ptr(x_in), L.ptr(y), _p(gate), _p(shift), _p(scale), mod_ld, L.ptr(x_out),
+           L.ptr(h), L.ptr(mean), L.ptr(rstd), B, T, D, eps, L.dt(x_in), L.stream())
+    return x_out, h, mean, rstd
+
+
+def add_ln_modulate_bwd(dh, x, mean, rstd, B, T, *, scale=None, dx_in=None, y=None, gate=None, mod_ld=0,
+                        dshift=None, dscale=None, dgate=None):
+    M, D = x.shape
+    dx = torch.empty_like(x)
+    dy = torch.empty_like(x) if y is not None else None
+    L.call("uwu_add_ln_modulate_bwd", L.ptr(dh), L.ptr(x), L.ptr(mean), L.ptr(rstd), _p(scale), L.ptr(dx_in),
+           L.ptr(y), _p(gate), mod_ld, L.ptr(dx), L.ptr(dy), _p(dshift), _p(dscale), _p(dgate), B, T, D, L.dt(x),
+           L.stream())
+    return dx, dy
+
+
+def _p(t):
+    """Pointer of a possibly non-contiguous *view* whose rows are addressed through an explicit stride."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise L.UwuError("device tensor required")
+    return t.data_ptr()
+
+
+def attention_fwd(q, k, v, B, Tq, Tk, H, d, scale=None):
+    """q/k/v: 2-D views [B*T, >=H*d] with unit inner stride (e.g. column slices of a packed projection)."""
+    scale = scale if scale is not None else d ** -0.5
+    o = torch.empty(B * Tq, H * d, device=q.device, dtype=q.dtype)
+    lse = torch.empty(B, H, Tq, device=q.device, dtype=torch.float32)
+    L.call("uwu_attention_fwd", _p(q), _p(k), _p(v), L.ptr(o), L.ptr(lse), B, Tq, Tk, H, d, q.stride(0), k.stride(0),
+           v.stride(0), o.stride(0), scale, L.dt(q), L.stream())
+    return o, lse
+
+
+def attention_bwd(q, k, v, o, do, lse, dq, dk, dv, B, Tq, Tk, H, d, scale=None):
+    scale = scale if scale is not None else d ** -0.5
+    delta = torch.empty_like(lse)
+    L.call("uwu_attention_bwd", _p(q), _p(k), _p(v), L.ptr(o), L.ptr(do), L.ptr(lse), L.ptr(delta), _p(dq), _p(dk),
+           _p(dv), B, Tq, Tk, H, d, q.stride(0), k.stride(0), v.stride(0), o.stride(0), scale, L.dt(q), L.stream())
+    return dq, dk, dv
+
+
+def colsum(x, out=None, accumulate=False):
+    M, N = x.shape
+    if out is None:
+        out = torch.empty(N, device=x.device, dtype=torch.float32)
+    L.call("uwu_colsum", L.ptr(x), L.dt(x), M, N, x.stride(0), L.ptr(out), int(accumulate), L.stream())
+    return out
