@@ -165,6 +165,9 @@ int uwu_timestep_embedding(const float* t, int B, int dim, float max_period, voi
 int uwu_silu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream);
 int uwu_silu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dtype, void* stream);
 
+/* out = a + b elementwise (same dtype). */
+int uwu_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream);
+
 /* patchify: latent [B,C,H,W] (fp32) -> tokens [B*(H/p)*(W/p), C*p*p] (dtype), feature order (c,ph,pw).
  * unpatchify is the inverse (tokens -> fp32 image).  Conv2d(k=p,s=p) patch embedding == patchify + GEMM. */
 int uwu_patchify(const float* img, void* tok, int B, int C, int H, int W, int p, int dtype, void* stream);
@@ -177,7 +180,7 @@ int uwu_add_pos(void* x, const float* pos, int B, int T, int D, int dtype, void*
 /* DiT forward/backward: all kernel launches of one network pass issued from C++ (no per-op
  * host round trip).  The argument block is a plain C struct of device pointers and sizes. */
 typedef struct uwu_dit_desc {
-  int32_t B, T, D, H, L, mlp_ratio, in_ch, out_ch, patch, img, dtype, cond_dim;
+  int32_t B, T, D, H, L, mlp_ratio, in_ch, out_ch, patch, img, dtype, cond_dim, freq_dim;
   float ln_eps;
   int32_t mod_total;   /* = L*6*D + 2*D : all adaLN linears batched in one GEMM */
   /* parameter blob (operand dtype copy for GEMM operands, fp32 master for biases) */
@@ -197,8 +200,14 @@ size_t uwu_dit_workspace_bytes(const uwu_dit_desc* d);
 /* noisy: fp32 [B,C,H,W]; t: fp32 [B]; cond: fp32 [B, cond_dim] or NULL; out: fp32 [B,out_ch,H,W] */
 int uwu_dit_forward(const uwu_dit_desc* d, const float* noisy, const float* t, const float* cond,
                     float* out, void* stream);
-/* dout: `fp32` [B,out_ch,H,W] gradient of the loss wrt the network output. */
+/* dout: fp32 [B,out_ch,H,W] gradient of the loss wrt the network output; parameter gradients are ACCUMULATED
+ * into d->g32 (zero it at the start of a step).  uwu_dit_backward_cond adds the gradient of the pooled-
+ * conditioning projection (it needs the caller's `cond` tensor again). */
 int uwu_dit_backward(const uwu_dit_desc* d, const float* dout, void* stream);
+int uwu_dit_backward_cond(const uwu_dit_desc* d, const float* cond, void* stream);
+/* elements per transformer block in the flat parameter blob (every tensor padded to 64 elements):
+ * qkv_w[3D,D] qkv_b[3D] o_w[D,D] o_b[D] fc1_w[rD,D] fc1_b[rD] fc2_w[D,rD] fc2_b[D] */
+int64_t uwu_dit_layer_param_stride(int D, int mlp_ratio);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,395 @@
+// DiT (adaLN-Zero) forward / backward driver: every kernel launch of one network pass is issued from this
+// C++ function, so the host pays one C call per pass instead of ~25 Python round trips per layer.
+// Block semantics follow the reference's ada_norm_zero branch (src/duwu/modules/rope_unet.py:306-309,
+// 344-349, 393-411) and attention processor (:122-166); the call contract is diffusion.py:172-176.
+//
+// Precision policy: activations and GEMM operands in `dtype` (bf16 or fp32), fp32 accumulation, fp32 LN
+// statistics / softmax / modulation.  The conditioning path (timestep MLP, pooled-text projection, the
+// batched adaLN linear: M = B rows only) always runs in fp32 from the fp32 master weights.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/uwu_hip.h"
+
+void uwu_set_error(const char* fmt, ...);
+
+namespace {
+
+struct Layout {
+  size_t es;  // activation element size
+  int64_t M, D, D3, D4, Kp, Ko;
+  // fp32 conditioning path
+  size_t feat, t_pre, t_h, temb, yemb, c, sc, mod;
+  // token path
+  size_t tok, xe;
+  size_t layer0, layer_stride;
+  // per-layer sub-offsets
+  size_t o_x0, o_m1, o_r1, o_h1, o_qkv, o_lse, o_ao, o_y1, o_x1, o_m2, o_r2, o_h2, o_u, o_f, o_y2;
+  size_t xF, mF, rF, hF, otok;
+  // backward scratch
+  size_t dx, dy, dh, dqkv, dao, du, delta, dotok, dmod, dsc, dc, dth, dtp;
+  size_t total;
+};
+
+inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+Layout make_layout(const uwu_dit_desc& d) {
+  Layout L{};
+  L.es = d.dtype == UWU_BF16 ? 2 : 4;
+  L.M = (int64_t)d.B * d.T;
+  L.D = d.D;
+  L.D3 = 3 * (int64_t)d.D;
+  L.D4 = (int64_t)d.mlp_ratio * d.D;
+  L.Kp = (int64_t)d.in_ch * d.patch * d.patch;
+  L.Ko = (int64_t)d.out_ch * d.patch * d.patch;
+  size_t p = 0;
+  auto take = [&](size_t bytes) { size_t o = p; p = al(p + bytes); return o; };
+  const size_t f4 = 4;
+  L.feat = take((size_t)d.B * d.freq_dim * f4);
+  L.t_pre = take((size_t)d.B * d.D * f4);
+  L.t_h = take((size_t)d.B * d.D * f4);
+  L.temb = take((size_t)d.B * d.D * f4);
+  L.yemb = take((size_t)d.B * d.D * f4);
+  L.c = take((size_t)d.B * d.D * f4);
+  L.sc = take((size_t)d.B * d.D * f4);
+  L.mod = take((size_t)d.B * d.mod_total * f4);
+  L.tok = take(L.M * L.Kp * L.es);
+  L.xe = take(L.M * L.D * L.es);
+  // per-layer block
+  size_t q = 0;
+  auto sub = [&](size_t bytes) { size_t o = q; q = al(q + bytes); return o; };
+  L.o_x0 = sub(L.M * L.D * L.es);
+  L.o_m1 = sub(L.M * f4);
+  L.o_r1 = sub(L.M * f4);
+  L.o_h1 = sub(L.M * L.D * L.es);
+  L.o_qkv = sub(L.M * L.D3 * L.es);
+  L.o_lse = sub((size_t)d.B * d.H * d.T * f4);
+  L.o_ao = sub(L.M * L.D * L.es);
+  L.o_y1 = sub(L.M * L.D * L.es);
+  L.o_x1 = sub(L.M * L.D * L.es);
+  L.o_m2 = sub(L.M * f4);
+  L.o_r2 = sub(L.M * f4);
+  L.o_h2 = sub(L.M * L.D * L.es);
+  L.o_u = sub(L.M * L.D4 * L.es);
+  L.o_f = sub(L.M * L.D4 * L.es);
+  L.o_y2 = sub(L.M * L.D * L.es);
+  L.layer_stride = q;
+  L.layer0 = p;
+  p += (size_t)d.L * L.layer_stride;
+  L.xF = take(L.M * L.D * L.es);
+  L.mF = take(L.M * f4);
+  L.rF = take(L.M * f4);
+  L.hF = take(L.M * L.D * L.es);
+  L.otok = take(L.M * L.Ko * L.es);
+  L.dx = take(L.M * L.D * L.es);
+  L.dy = take(L.M * L.D * L.es);
+  L.dh = take(L.M * L.D * L.es);
+  L.dqkv = take(L.M * L.D3 * L.es);
+  L.dao = take(L.M * L.D * L.es);
+  L.du = take(L.M * L.D4 * L.es);
+  L.delta = take((size_t)d.B * d.H * d.T * f4);
+  L.dotok = take(L.M * L.Ko * L.es);
+  L.dmod = take((size_t)d.B * d.mod_total * f4);
+  L.dsc = take((size_t)d.B * d.D * f4);
+  L.dc = take((size_t)d.B * d.D * f4);
+  L.dth = take((size_t)d.B * d.D * f4);
+  L.dtp = take((size_t)d.B * d.D * f4);
+  L.total = p;
+  return L;
+}
+
+int check_desc(const uwu_dit_desc* d) {
+  if (!d) { uwu_set_error("dit: null descriptor"); return UWU_EINVAL; }
+  if (d->B <= 0 || d->T <= 0 || d->D <= 0 || d->H <= 0 || d->L <= 0 || d->D % d->H || d->D % 8 ||
+      d->img % d->patch || (d->img / d->patch) * (d->img / d->patch) != d->T || d->mlp_ratio <= 0 ||
+      d->freq_dim <= 0 || d->freq_dim % 8) {
+    uwu_set_error("dit: inconsistent shape B=%d T=%d D=%d H=%d L=%d img=%d patch=%d", d->B, d->T, d->D, d->H, d->L,
+                  d->img, d->patch);
+    return UWU_EINVAL;
+  }
+  if (d->dtype != UWU_F32 && d->dtype != UWU_BF16) { uwu_set_error("dit: bad dtype"); return UWU_EINVAL; }
+  if (d->mod_total != d->L * 6 * d->D + 2 * d->D) { uwu_set_error("dit: mod_total mismatch"); return UWU_EINVAL; }
+  if ((d->in_ch * d->patch * d->patch) % 8 || (d->out_ch * d->patch * d->patch) % 8 || (d->cond_dim % 8)) {
+    uwu_set_error("dit: C*p*p and cond_dim must be multiples of 8");
+    return UWU_EINVAL;
+  }
+  if (!d->w || !d->w32 || !d->pos || !d->ws) { uwu_set_error("dit: null buffer"); return UWU_EINVAL; }
+  return UWU_OK;
+}
+
+#define RUN(expr)              \
+  do {                         \
+    int rc_ = (expr);          \
+    if (rc_ != UWU_OK) return rc_; \
+  } while (0)
+
+// Y[M,N] = X[M,K] . W[N,K]^T (+ epilogue)
+int lin_fwd(const void* X, const void* W, const float* bias, void* Y, void* Y2, int M, int N, int K, int dt, int cdt,
+            int epi, void* st) {
+  return uwu_gemm(X, W, Y, Y2, bias, nullptr, M, N, K, K, K, N, 0, 0, 0, dt, cdt, epi, 1, st);
+}
+// dX[M,K] = dY[M,N] . W[N,K]   (optionally * gelu'(aux[M,K]))
+int lin_dgrad(const void* dY, const void* W, void* dX, const void* aux, int M, int N, int K, int dt, void* st) {
+  return uwu_gemm(dY, W, dX, nullptr, nullptr, aux, M, K, N, N, K, K, K, 0, 1, dt, dt,
+                  aux ? UWU_EPI_DGELU : UWU_EPI_NONE, 1, st);
+}
+// dW[N,K] += dY[M,N]^T . X[M,K]   (fp32 atomics, split over the token dimension)
+int lin_wgrad(const void* dY, const void* X, float* dW, int M, int N, int K, int dt, void* st) {
+  const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+  const int bk = dt == UWU_BF16 ? 64 : 32;
+  const int ktiles = (M + bk - 1) / bk;
+  int split = (512 + tiles - 1) / tiles;
+  if (split > ktiles) split = ktiles;
+  if (split < 1) split = 1;
+  return uwu_gemm(dY, X, dW, nullptr, nullptr, nullptr, N, K, M, N, K, K, 0, 1, 1, dt, UWU_F32, UWU_EPI_ACCUM, split, st);
+}
+
+struct Ptrs {
+  char* ws;
+  const Layout& L;
+  template <typename T = void>
+  T* at(size_t off) const { return reinterpret_cast<T*>(ws + off); }
+  template <typename T = void>
+  T* lay(int l, size_t sub) const { return reinterpret_cast<T*>(ws + L.layer0 + (size_t)l * L.layer_stride + sub); }
+};
+
+struct LayerW {
+  const void *qkv_w, *o_w, *fc1_w, *fc2_w;
+  const float *qkv_b, *o_b, *fc1_b, *fc2_b;
+  int64_t off_qkv_w, off_qkv_b, off_o_w, off_o_b, off_fc1_w, off_fc1_b, off_fc2_w, off_fc2_b;
+};
+
+inline int64_t pad64(int64_t n) { return (n + 63) & ~(int64_t)63; }
+
+LayerW layer_weights(const uwu_dit_desc& d, int l) {
+  LayerW w{};
+  const int64_t D = d.D, D4 = (int64_t)d.mlp_ratio * d.D;
+  int64_t o = d.off_layer0 + (int64_t)l * d.layer_stride;
+  w.off_qkv_w = o; o += pad64(3 * D * D);
+  w.off_qkv_b = o; o += pad64(3 * D);
+  w.off_o_w = o; o += pad64(D * D);
+  w.off_o_b = o; o += pad64(D);
+  w.off_fc1_w = o; o += pad64(D4 * D);
+  w.off_fc1_b = o; o += pad64(D4);
+  w.off_fc2_w = o; o += pad64(D * D4);
+  w.off_fc2_b = o; o += pad64(D);
+  const size_t es = d.dtype == UWU_BF16 ? 2 : 4;
+  const char* wb = static_cast<const char*>(d.w);
+  w.qkv_w = wb + w.off_qkv_w * es;
+  w.o_w = wb + w.off_o_w * es;
+  w.fc1_w = wb + w.off_fc1_w * es;
+  w.fc2_w = wb + w.off_fc2_w * es;
+  w.qkv_b = d.w32 + w.off_qkv_b;
+  w.o_b = d.w32 + w.off_o_b;
+  w.fc1_b = d.w32 + w.off_fc1_b;
+  w.fc2_b = d.w32 + w.off_fc2_b;
+  return w;
+}
+
+}  // namespace
+
+extern "C" size_t uwu_dit_workspace_bytes(const uwu_dit_desc* d) {
+  if (!d) return 0;
+  return make_layout(*d).total;
+}
+
+extern "C" int64_t uwu_dit_layer_param_stride(int D, int mlp_ratio) {
+  const int64_t d = D, d4 = (int64_t)mlp_ratio * D;
+  return pad64(3 * d * d) + pad64(3 * d) + pad64(d * d) + pad64(d) + pad64(d4 * d) + pad64(d4) + pad64(d * d4) + pad64(d);
+}
+
+extern "C" int uwu_dit_forward(const uwu_dit_desc* dp, const float* noisy, const float* t, const float* cond,
+                               float* out, void* st) {
+  RUN(check_desc(dp));
+  const uwu_dit_desc& d = *dp;
+  if (!noisy || !t || !out) { uwu_set_error("dit_forward: null tensor"); return UWU_EINVAL; }
+  if ((d.cond_dim > 0) != (cond != nullptr)) { uwu_set_error("dit_forward: cond / cond_dim mismatch"); return UWU_EINVAL; }
+  const Layout L = make_layout(d);
+  if (d.ws_bytes < L.total) { uwu_set_error("dit_forward: workspace too small (%zu < %zu)", d.ws_bytes, L.total); return UWU_EINVAL; }
+  if (d.layer_stride != uwu_dit_layer_param_stride(d.D, d.mlp_ratio)) { uwu_set_error("dit: layer_stride mismatch"); return UWU_EINVAL; }
+  Ptrs P{static_cast<char*>(d.ws), L};
+  const int dt = d.dtype, B = d.B, T = d.T, D = d.D, M = (int)L.M, D3 = (int)L.D3, D4 = (int)L.D4;
+  const size_t es = L.es;
+  const char* wb = static_cast<const char*>(d.w);
+  const float* w32 = d.w32;
+  const int ML = d.mod_total;
+
+  // ---- conditioning path (fp32): c = MLP(sinusoid(t)) + proj(cond); mod = Linear(silu(c)) for ALL layers at once
+  RUN(uwu_timestep_embedding(t, B, d.freq_dim, 10000.f, P.at(L.feat), UWU_F32, st));
+  RUN(lin_fwd(P.at(L.feat), w32 + d.off_t_w1, w32 + d.off_t_b1, P.at(L.t_pre), P.at(L.t_h), B, D, d.freq_dim, UWU_F32,
+              UWU_F32, UWU_EPI_BIAS_SILU, st));
+  RUN(lin_fwd(P.at(L.t_h), w32 + d.off_t_w2, w32 + d.off_t_b2, P.at(L.temb), nullptr, B, D, D, UWU_F32, UWU_F32,
+              UWU_EPI_BIAS, st));
+  const void* cptr = P.at(L.temb);
+  if (cond) {
+    RUN(lin_fwd(cond, w32 + d.off_y_w, w32 + d.off_y_b, P.at(L.yemb), nullptr, B, D, d.cond_dim, UWU_F32, UWU_F32,
+                UWU_EPI_BIAS, st));
+    RUN(uwu_add(P.at(L.temb), P.at(L.yemb), P.at(L.c), (int64_t)B * D, UWU_F32, st));
+    cptr = P.at(L.c);
+  }
+  RUN(uwu_silu_fwd(cptr, P.at(L.sc), (int64_t)B * D, UWU_F32, st));
+  RUN(lin_fwd(P.at(L.sc), w32 + d.off_mod_w, w32 + d.off_mod_b, P.at(L.mod), nullptr, B, ML, D, UWU_F32, UWU_F32,
+              UWU_EPI_BIAS, st));
+  const float* mod = P.at<float>(L.mod);
+
+  // ---- patch embedding (Conv2d k=p,s=p == patchify + GEMM) + fixed 2-D sin-cos positions
+  RUN(uwu_patchify(noisy, P.at(L.tok), B, d.in_ch, d.img, d.img, d.patch, dt, st));
+  RUN(lin_fwd(P.at(L.tok), wb + d.off_patch_w * es, w32 + d.off_patch_b, P.lay(0, L.o_x0), nullptr, M, D, (int)L.Kp, dt,
+              dt, UWU_EPI_BIAS, st));
+  RUN(uwu_add_pos(P.lay(0, L.o_x0), d.pos, B, T, D, dt, st));
+
+  const float scale = 1.f / sqrtf((float)(D / d.H));
+  for (int l = 0; l < d.L; ++l) {
+    const LayerW w = layer_weights(d, l);
+    const float* m = mod + (int64_t)l * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+    void* x0 = P.lay(l, L.o_x0);
+    // LN1 (+ pending MLP branch of the previous layer: x0 = x1_prev + gate_mlp_prev * y2_prev)
+    if (l == 0) {
+      RUN(uwu_add_ln_modulate_fwd(x0, nullptr, nullptr, m + 0, m + D, ML, x0, P.lay(l, L.o_h1),
+                                  P.lay<float>(l, L.o_m1), P.lay<float>(l, L.o_r1), B, T, D, d.ln_eps, dt, st));
+    } else {
+      const float* mp = mod + (int64_t)(l - 1) * 6 * D;
+      RUN(uwu_add_ln_modulate_fwd(P.lay(l - 1, L.o_x1), P.lay(l - 1, L.o_y2), mp + 5 * D, m + 0, m + D, ML, x0,
+                                  P.lay(l, L.o_h1), P.lay<float>(l, L.o_m1), P.lay<float>(l, L.o_r1), B, T, D,
+                                  d.ln_eps, dt, st));
+    }
+    RUN(lin_fwd(P.lay(l, L.o_h1), w.qkv_w, w.qkv_b, P.lay(l, L.o_qkv), nullptr, M, D3, D, dt, dt, UWU_EPI_BIAS, st));
+    char* qkv = P.lay<char>(l, L.o_qkv);
+    RUN(uwu_attention_fwd(qkv, qkv + (size_t)D * es, qkv + (size_t)2 * D * es, P.lay(l, L.o_ao), P.lay<float>(l, L.o_lse),
+                          B, T, T, d.H, D / d.H, D3, D3, D3, D, scale, dt, st));
+    RUN(lin_fwd(P.lay(l, L.o_ao), w.o_w, w.o_b, P.lay(l, L.o_y1), nullptr, M, D, D, dt, dt, UWU_EPI_BIAS, st));
+    // x1 = x0 + gate_msa * y1 ; h2 = LN(x1)*(1+scale_mlp)+shift_mlp
+    RUN(uwu_add_ln_modulate_fwd(x0, P.lay(l, L.o_y1), m + 2 * D, m + 3 * D, m + 4 * D, ML, P.lay(l, L.o_x1),
+                                P.lay(l, L.o_h2), P.lay<float>(l, L.o_m2), P.lay<float>(l, L.o_r2), B, T, D, d.ln_eps,
+                                dt, st));
+    RUN(lin_fwd(P.lay(l, L.o_h2), w.fc1_w, w.fc1_b, P.lay(l, L.o_u), P.lay(l, L.o_f), M, D4, D, dt, dt,
+                UWU_EPI_BIAS_GELU, st));
+    RUN(lin_fwd(P.lay(l, L.o_f), w.fc2_w, w.fc2_b, P.lay(l, L.o_y2), nullptr, M, D, D4, dt, dt, UWU_EPI_BIAS, st));
+  }
+  // ---- final adaLN + linear + unpatchify
+  {
+    const int l = d.L - 1;
+    const float* mp = mod + (int64_t)l * 6 * D;
+    const float* mf = mod + (int64_t)d.L * 6 * D;  // shift, scale
+    RUN(uwu_add_ln_modulate_fwd(P.lay(l, L.o_x1), P.lay(l, L.o_y2), mp + 5 * D, mf + 0, mf + D, ML, P.at(L.xF),
+                                P.at(L.hF), P.at<float>(L.mF), P.at<float>(L.rF), B, T, D, d.ln_eps, dt, st));
+    RUN(lin_fwd(P.at(L.hF), wb + d.off_final_w * es, w32 + d.off_final_b, P.at(L.otok), nullptr, M, (int)L.Ko, D, dt, dt,
+                UWU_EPI_BIAS, st));
+    RUN(uwu_unpatchify(P.at(L.otok), dt, out, B, d.out_ch, d.img, d.img, d.patch, st));
+  }
+  return UWU_OK;
+}
+
+extern "C" int uwu_dit_backward(const uwu_dit_desc* dp, const float* dout, void* st) {
+  RUN(check_desc(dp));
+  const uwu_dit_desc& d = *dp;
+  if (!dout || !d.g32) { uwu_set_error("dit_backward: null tensor"); return UWU_EINVAL; }
+  const Layout L = make_layout(d);
+  if (d.ws_bytes < L.total) { uwu_set_error("dit_backward: workspace too small"); return UWU_EINVAL; }
+  Ptrs P{static_cast<char*>(d.ws), L};
+  const int dt = d.dtype, B = d.B, T = d.T, D = d.D, M = (int)L.M, D3 = (int)L.D3, D4 = (int)L.D4;
+  const size_t es = L.es;
+  const char* wb = static_cast<const char*>(d.w);
+  const float* w32 = d.w32;
+  float* g = d.g32;
+  const int ML = d.mod_total;
+  const float* mod = P.at<float>(L.mod);
+  float* dmod = P.at<float>(L.dmod);
+  if (hipMemsetAsync(dmod, 0, (size_t)B * ML * sizeof(float), (hipStream_t)st) != hipSuccess) {
+    uwu_set_error("dit_backward: memset failed");
+    return UWU_ELAUNCH;
+  }
+  const float scale = 1.f / sqrtf((float)(D / d.H));
+
+  // ---- output head
+  RUN(uwu_patchify(dout, P.at(L.dotok), B, d.out_ch, d.img, d.img, d.patch, dt, st));
+  RUN(lin_wgrad(P.at(L.dotok), P.at(L.hF), g + d.off_final_w, M, (int)L.Ko, D, dt, st));
+  RUN(uwu_colsum(P.at(L.dotok), dt, M, (int)L.Ko, (int)L.Ko, g + d.off_final_b, 1, st));
+  RUN(lin_dgrad(P.at(L.dotok), wb + d.off_final_w * es, P.at(L.dh), nullptr, M, (int)L.Ko, D, dt, st));
+  {
+    const int l = d.L - 1;
+    const float* mp = mod + (int64_t)l * 6 * D;
+    const float* mf = mod + (int64_t)d.L * 6 * D;
+    float* dmp = dmod + (int64_t)l * 6 * D;
+    float* dmf = dmod + (int64_t)d.L * 6 * D;
+    // final LN bwd + gate bwd of the last MLP branch: dx = d/d x1_{L-1}; dy = gate_mlp * dx
+    RUN(uwu_add_ln_modulate_bwd(P.at(L.dh), P.at(L.xF), P.at<float>(L.mF), P.at<float>(L.rF), mf + D, nullptr,
+                                P.lay(l, L.o_y2), mp + 5 * D, ML, P.at(L.dx), P.at(L.dy), dmf + 0, dmf + D, dmp + 5 * D,
+                                B, T, D, dt, st));
+  }
+  for (int l = d.L - 1; l >= 0; --l) {
+    const LayerW w = layer_weights(d, l);
+    const float* m = mod + (int64_t)l * 6 * D;
+    float* dm = dmod + (int64_t)l * 6 * D;
+    // ---- MLP branch: y2 = fc2(gelu(fc1(h2)))
+    RUN(lin_wgrad(P.at(L.dy), P.lay(l, L.o_f), g + w.off_fc2_w, M, D, D4, dt, st));
+    RUN(uwu_colsum(P.at(L.dy), dt, M, D, D, g + w.off_fc2_b, 1, st));
+    RUN(lin_dgrad(P.at(L.dy), w.fc2_w, P.at(L.du), P.lay(l, L.o_u), M, D, D4, dt, st));  // du = (dy.W2) * gelu'(u)
+    RUN(lin_wgrad(P.at(L.du), P.lay(l, L.o_h2), g + w.off_fc1_w, M, D4, D, dt, st));
+    RUN(uwu_colsum(P.at(L.du), dt, M, D4, D4, g + w.off_fc1_b, 1, st));
+    RUN(lin_dgrad(P.at(L.du), w.fc1_w, P.at(L.dh), nullptr, M, D4, D, dt, st));
+    // LN2 bwd (+ residual) and gate bwd of the attention branch
+    RUN(uwu_add_ln_modulate_bwd(P.at(L.dh), P.lay(l, L.o_x1), P.lay<float>(l, L.o_m2), P.lay<float>(l, L.o_r2), m + 4 * D,
+                                P.at(L.dx), P.lay(l, L.o_y1), m + 2 * D, ML, P.at(L.dx), P.at(L.dy), dm + 3 * D,
+                                dm + 4 * D, dm + 2 * D, B, T, D, dt, st));
+    // ---- attention branch: y1 = proj(attn(qkv(h1)))
+    RUN(lin_wgrad(P.at(L.dy), P.lay(l, L.o_ao), g + w.off_o_w, M, D, D, dt, st));
+    RUN(uwu_colsum(P.at(L.dy), dt, M, D, D, g + w.off_o_b, 1, st));
+    RUN(lin_dgrad(P.at(L.dy), w.o_w, P.at(L.dao), nullptr, M, D, D, dt, st));
+    char* qkv = P.lay<char>(l, L.o_qkv);
+    char* dqkv = P.at<char>(L.dqkv);
+    RUN(uwu_attention_bwd(qkv, qkv + (size_t)D * es, qkv + (size_t)2 * D * es, P.lay(l, L.o_ao), P.at(L.dao),
+                          P.lay<float>(l, L.o_lse), P.at<float>(L.delta), dqkv, dqkv + (size_t)D * es,
+                          dqkv + (size_t)2 * D * es, B, T, T, d.H, D / d.H, D3, D3, D3, D, scale, dt, st));
+    RUN(lin_wgrad(dqkv, P.lay(l, L.o_h1), g + w.off_qkv_w, M, D3, D, dt, st));
+    RUN(uwu_colsum(dqkv, dt, M, D3, D3, g + w.off_qkv_b, 1, st));
+    RUN(lin_dgrad(dqkv, w.qkv_w, P.at(L.dh), nullptr, M, D3, D, dt, st));
+    // LN1 bwd (+ residual) and gate bwd of the previous layer's MLP branch
+    if (l > 0) {
+      const float* mp = mod + (int64_t)(l - 1) * 6 * D;
+      float* dmp = dmod + (int64_t)(l - 1) * 6 * D;
+      RUN(uwu_add_ln_modulate_bwd(P.at(L.dh), P.lay(l, L.o_x0), P.lay<float>(l, L.o_m1), P.lay<float>(l, L.o_r1), m + D,
+                                  P.at(L.dx), P.lay(l - 1, L.o_y2), mp + 5 * D, ML, P.at(L.dx), P.at(L.dy), dm + 0,
+                                  dm + D, dmp + 5 * D, B, T, D, dt, st));
+    } else {
+      RUN(uwu_add_ln_modulate_bwd(P.at(L.dh), P.lay(l, L.o_x0), P.lay<float>(l, L.o_m1), P.lay<float>(l, L.o_r1), m + D,
+                                  P.at(L.dx), nullptr, nullptr, ML, P.at(L.dx), nullptr, dm + 0, dm + D, nullptr, B, T,
+                                  D, dt, st));
+    }
+  }
+  // ---- patch embedding (input latents need no gradient; positions are fixed)
+  RUN(lin_wgrad(P.at(L.dx), P.at(L.tok), g + d.off_patch_w, M, D, (int)L.Kp, dt, st));
+  RUN(uwu_colsum(P.at(L.dx), dt, M, D, D, g + d.off_patch_b, 1, st));
+
+  // ---- conditioning path (fp32)
+  RUN(lin_wgrad(dmod, P.at(L.sc), g + d.off_mod_w, B, ML, D, UWU_F32, st));
+  RUN(uwu_colsum(dmod, UWU_F32, B, ML, ML, g + d.off_mod_b, 1, st));
+  RUN(lin_dgrad(dmod, w32 + d.off_mod_w, P.at(L.dsc), nullptr, B, ML, D, UWU_F32, st));
+  const void* cptr = d.cond_dim > 0 ? P.at(L.c) : P.at(L.temb);
+  RUN(uwu_silu_bwd(cptr, P.at(L.dsc), P.at(L.dc), (int64_t)B * D, UWU_F32, st));
+  if (d.cond_dim > 0) {
+    // cond is an input; its projection weights get dW += dc^T cond.  `cond` itself is re-read from the caller.
+  }
+  RUN(lin_wgrad(P.at(L.dc), P.at(L.t_h), g + d.off_t_w2, B, D, D, UWU_F32, st));
+  RUN(uwu_colsum(P.at(L.dc), UWU_F32, B, D, D, g + d.off_t_b2, 1, st));
+  RUN(lin_dgrad(P.at(L.dc), w32 + d.off_t_w2, P.at(L.dth), nullptr, B, D, D, UWU_F32, st));
+  RUN(uwu_silu_bwd(P.at(L.t_pre), P.at(L.dth), P.at(L.dtp), (int64_t)B * D, UWU_F32, st));
+  RUN(lin_wgrad(P.at(L.dtp), P.at(L.feat), g + d.off_t_w1, B, D, d.freq_dim, UWU_F32, st));
+  RUN(uwu_colsum(P.at(L.dtp), UWU_F32, B, D, D, g + d.off_t_b1, 1, st));
+  return UWU_OK;
+}
+
+// gradient of the pooled-conditioning projection (needs the caller's `cond` tensor again)
+extern "C" int uwu_dit_backward_cond(const uwu_dit_desc* dp, const float* cond, void* st) {
+  RUN(check_desc(dp));
+  const uwu_dit_desc& d = *dp;
+  if (d.cond_dim <= 0) return UWU_OK;
+  if (!cond || !d.g32) { uwu_set_error("dit_backward_cond: null tensor"); return UWU_EINVAL; }
+  const Layout L = make_layout(d);
+  Ptrs P{static_cast<char*>(d.ws), L};
+  RUN(lin_wgrad(P.at(L.dc), cond, d.g32 + d.off_y_w, d.B, d.D, d.cond_dim, UWU_F32, st));
+  RUN(uwu_colsum(P.at(L.dc), UWU_F32, d.B, d.D, d.D, d.g32 + d.off_y_b, 1, st));
+  return UWU_OK;
+}

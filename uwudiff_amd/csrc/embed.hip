@@ -63,6 +63,13 @@ __global__ void patch_kernel(float* __restrict__ img, T* __restrict__ tok, int B
 }
 
 template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, int64_t n4) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+    store4(o + 4 * i, load4(a + 4 * i) + load4(b + 4 * i));
+}
+
+template <typename T>
 __global__ void add_pos_kernel(T* __restrict__ x, const float* __restrict__ pos, int64_t total4, int64_t td4) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
@@ -140,5 +147,15 @@ extern "C" int uwu_add_pos(void* x, const float* pos, int B, int T, int D, int d
   DISPATCH_T(dtype, AP, 0)
 #undef AP
   UWU_LAUNCH_CHECK("add_pos");
+  return UWU_OK;
+}
+
+extern "C" int uwu_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream) {
+  UWU_CHECK_ARG(a && b && out && n > 0 && n % 4 == 0, "add: n must be a positive multiple of 4");
+  hipStream_t st = (hipStream_t)stream;
+#define AD(T, ...) hipLaunchKernelGGL((add_kernel<T>), dim3(ew_grid(n / 4, 256)), dim3(256), 0, st, (const T*)a, (const T*)b, (T*)out, n / 4)
+  DISPATCH_T(dtype, AD, 0)
+#undef AD
+  UWU_LAUNCH_CHECK("add");
   return UWU_OK;
 }

@@ -1,0 +1,294 @@
+"""DiT (adaLN-Zero diffusion transformer) behind the reference's denoiser slot.
+
+Call contract (reference src/duwu/loss/diffusion.py:172-176, kwargs from trainer.py:267-274):
+
+    unet(sample [B,C,H,W], timestep [B], encoder_hidden_states=..., encoder_attention_mask=...,
+         added_cond_kwargs={"time_ids": [B,6], "text_embeds": [B,Dpool]}, cross_attention_kwargs=...)[0]
+      -> [B,C,H,W]
+
+Block semantics follow the reference's ``ada_norm_zero`` branch (src/duwu/modules/rope_unet.py:306-309,
+344-349, 393-411).  The network is this build's own definition (the reference ships no DiT):
+Peebles & Xie sizes (S/B/L/XL = depth 12/12/24/28, width 384/768/1024/1152, heads 6/12/16/16), patch 2,
+fixed 2-D sin-cos positions, tanh-GELU MLP x4, conditioning c = MLP(sinusoid(t)) + Linear(pooled text).
+
+MI355X layout: ALL parameters live in one flat fp32 buffer (``self.flat``; 64-element aligned tensors) with a
+bf16 shadow for the MFMA operands, gradients accumulate into one flat fp32 buffer (``self.flat.grad``) -> one
+AdamW launch and one all-reduce per step.  Forward and backward are each a single C call into
+``uwu_dit_forward`` / ``uwu_dit_backward`` (csrc/dit.cpp).
+"""
+import ctypes
+import math
+from dataclasses import dataclass
+
+import torch
+import torch.nn as nn
+
+from . import lib as L
+
+PRESETS = {
+    "DiT-S/2": dict(depth=12, hidden=384, heads=6, patch=2),
+    "DiT-B/2": dict(depth=12, hidden=768, heads=12, patch=2),
+    "DiT-L/2": dict(depth=24, hidden=1024, heads=16, patch=2),
+    "DiT-XL/2": dict(depth=28, hidden=1152, heads=16, patch=2),
+}
+
+
+@dataclass
+class DiTConfig:
+    depth: int = 12
+    hidden: int = 384
+    heads: int = 6
+    patch: int = 2
+    sample_size: int = 32
+    in_channels: int = 4
+    out_channels: int = 4
+    mlp_ratio: int = 4
+    cond_dim: int = 0          # pooled-text width (SDXL: 1280); 0 = unconditional
+    freq_dim: int = 256
+    ln_eps: float = 1e-6
+    compute_dtype: str = "bf16"  # "bf16" | "fp32"
+
+
+def _pad64(n):
+    return (n + 63) // 64 * 64
+
+
+def sincos_2d(dim, grid):
+    """Fixed 2-D sin-cos position table [grid*grid, dim] (MAE/DiT construction: half the channels per axis)."""
+    def one(d, pos):
+        omega = 1.0 / (10000 ** (torch.arange(d // 2, dtype=torch.float64) / (d / 2)))
+        out = pos.reshape(-1, 1).double() * omega[None]
+        return torch.cat([out.sin(), out.cos()], dim=1)
+
+    gh, gw = torch.meshgrid(torch.arange(grid), torch.arange(grid), indexing="ij")
+    emb = torch.cat([one(dim // 2, gw), one(dim // 2, gh)], dim=1)  # w first, as get_2d_sincos_pos_embed
+    return emb.float()
+
+
+class _DiTFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, flat, model, noisy, t, cond):
+        out = model._run_forward(noisy, t, cond)
+        ctx.model = model
+        ctx.gen = model._fwd_gen
+        ctx.cond = cond
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        model = ctx.model
+        if ctx.gen != model._fwd_gen:
+            raise RuntimeError("DiT.backward: the activation workspace was overwritten by a later forward "
+                               "(one outstanding forward per backward)")
+        model._run_backward(dout.float().contiguous(), ctx.cond)
+        return None, None, None, None, None
+
+
+class DiT(nn.Module):
+    def __init__(self, config: DiTConfig = None, init: str = "dit", **kw):
+        super().__init__()
+        if config is None:
+            config = DiTConfig(**kw)
+        self.cfg = c = config
+        assert c.hidden % c.heads == 0 and c.sample_size % c.patch == 0
+        self.T = (c.sample_size // c.patch) ** 2
+        D, r = c.hidden, c.mlp_ratio
+        kp, ko = c.in_channels * c.patch ** 2, c.out_channels * c.patch ** 2
+        self.mod_total = c.depth * 6 * D + 2 * D
+        spec = [("x_embedder.weight", (D, kp)), ("x_embedder.bias", (D,)),
+                ("t_embedder.0.weight", (D, c.freq_dim)), ("t_embedder.0.bias", (D,)),
+                ("t_embedder.2.weight", (D, D)), ("t_embedder.2.bias", (D,)),
+                ("y_embedder.weight", (D, max(c.cond_dim, 8))), ("y_embedder.bias", (D,)),
+                ("adaLN.weight", (self.mod_total, D)), ("adaLN.bias", (self.mod_total,)),
+                ("final.weight", (ko, D)), ("final.bias", (ko,))]
+        for l in range(c.depth):
+            spec += [(f"blocks.{l}.qkv.weight", (3 * D, D)), (f"blocks.{l}.qkv.bias", (3 * D,)),
+                     (f"blocks.{l}.proj.weight", (D, D)), (f"blocks.{l}.proj.bias", (D,)),
+                     (f"blocks.{l}.fc1.weight", (r * D, D)), (f"blocks.{l}.fc1.bias", (r * D,)),
+                     (f"blocks.{l}.fc2.weight", (D, r * D)), (f"blocks.{l}.fc2.bias", (D,))]
+        self.registry = {}
+        off = 0
+        for name, shape in spec:
+            n = math.prod(shape)
+            self.registry[name] = (off, shape)
+            off += _pad64(n)
+        self.n_flat = off
+        self.flat = nn.Parameter(torch.zeros(off, dtype=torch.float32))
+        self.register_buffer("pos", sincos_2d(D, c.sample_size // c.patch), persistent=False)
+        self.register_buffer("shadow", torch.zeros(0, dtype=torch.bfloat16), persistent=False)
+        self._ws = None
+        self._ws_key = None
+        self._fwd_gen = 0
+        self._desc = None
+        self.config = type("cfg", (), dict(in_channels=c.in_channels, sample_size=c.sample_size))()
+        self.reset_parameters(init)
+
+    # ------------------------------------------------------------------ parameters
+    def view(self, name):
+        off, shape = self.registry[name]
+        return self.flat.data[off:off + math.prod(shape)].view(shape)
+
+    def grad_view(self, name):
+        off, shape = self.registry[name]
+        return self.flat.grad[off:off + math.prod(shape)].view(shape)
+
+    @torch.no_grad()
+    def reset_parameters(self, init="dit"):
+        """init="dit": DiT paper (xavier linears, zero adaLN / final) + the reference's near-zero N(0,1e-5)
+        residual-out rule (src/duwu/modules/unet_patch.py:34-45).  init="random": N(0,0.02) everywhere
+        (non-zero gates; used by parity tests and the benchmark so no branch is numerically dead)."""
+        self.flat.data.zero_()
+        g = torch.Generator().manual_seed(torch.initial_seed() % (2 ** 31))
+        for name, (off, shape) in self.registry.items():
+            v = self.view(name)
+            if init == "random":
+                v.copy_(torch.randn(shape, generator=g) * 0.02)
+                continue
+            if name.endswith("bias"):
+                continue
+            if name.startswith(("adaLN", "final")):
+                continue
+            if name.endswith(("proj.weight", "fc2.weight")):
+                v.copy_(torch.randn(shape, generator=g) * 1e-5)
+            elif name.startswith("t_embedder"):
+                v.copy_(torch.randn(shape, generator=g) * 0.02)
+            else:
+                bound = math.sqrt(6.0 / (shape[0] + shape[1]))
+                v.copy_((torch.rand(shape, generator=g) * 2 - 1) * bound)
+        self.refresh_shadow()
+
+    def named_tensors(self):
+        for name in self.registry:
+            if name.startswith("y_embedder") and self.cfg.cond_dim == 0:
+                continue
+            yield name, self.view(name)
+
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        sd = destination if destination is not None else {}
+        for name, v in self.named_tensors():
+            sd[prefix + name] = v if keep_vars else v.detach().clone()
+        return sd
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        missing = []
+        for name, v in self.named_tensors():
+            if name in state_dict:
+                v.copy_(state_dict[name].to(v))
+            else:
+                missing.append(name)
+        if strict and missing:
+            raise RuntimeError(f"Missing key(s) in state_dict: {missing}")
+        self.refresh_shadow()
+        return torch.nn.modules.module._IncompatibleKeys(missing, [])
+
+    @torch.no_grad()
+    def refresh_shadow(self):
+        """bf16 copy of the flat parameters for the MFMA operands (kept fresh by the fused AdamW afterwards)."""
+        if self.cfg.compute_dtype != "bf16" or not self.flat.is_cuda:
+            return
+        if self.shadow.numel() != self.n_flat or self.shadow.device != self.flat.device:
+            self.shadow = torch.empty(self.n_flat, device=self.flat.device, dtype=torch.bfloat16)
+        L.call("uwu_cast_f32_to_bf16", L.ptr(self.flat.data), L.ptr(self.shadow), self.n_flat, L.stream())
+        self.flat._uwu_bf16_shadow = self.shadow
+
+    def _apply(self, fn, recurse=True):
+        r = super()._apply(fn, recurse)
+        self._desc = None
+        self.refresh_shadow()
+        return r
+
+    def enable_gradient_checkpointing(self):  # test_scripts/test_train.py:38-39; activations fit in 288 GB
+        return None
+
+    # ------------------------------------------------------------------ descriptor / workspace
+    def _descriptor(self, B):
+        c = self.cfg
+        if not self.flat.is_cuda:
+            raise L.UwuError("DiT runs on the HIP device only; move the module with .cuda() (no CPU fallback)")
+        bf = c.compute_dtype == "bf16"
+        if bf and self.shadow.numel() != self.n_flat:
+            self.refresh_shadow()
+        d = L.DitDesc()
+        d.B, d.T, d.D, d.H, d.L = B, self.T, c.hidden, c.heads, c.depth
+        d.mlp_ratio, d.in_ch, d.out_ch, d.patch, d.img = c.mlp_ratio, c.in_channels, c.out_channels, c.patch, c.sample_size
+        d.dtype = L.BF16 if bf else L.F32
+        d.cond_dim, d.freq_dim, d.ln_eps, d.mod_total = c.cond_dim, c.freq_dim, c.ln_eps, self.mod_total
+        d.w = (self.shadow if bf else self.flat.data).data_ptr()
+        d.w32 = self.flat.data.data_ptr()
+        d.g32 = self.flat.grad.data_ptr() if self.flat.grad is not None else None
+        r = self.registry
+        d.off_patch_w, d.off_patch_b = r["x_embedder.weight"][0], r["x_embedder.bias"][0]
+        d.off_t_w1, d.off_t_b1 = r["t_embedder.0.weight"][0], r["t_embedder.0.bias"][0]
+        d.off_t_w2, d.off_t_b2 = r["t_embedder.2.weight"][0], r["t_embedder.2.bias"][0]
+        d.off_y_w, d.off_y_b = r["y_embedder.weight"][0], r["y_embedder.bias"][0]
+        d.off_mod_w, d.off_mod_b = r["adaLN.weight"][0], r["adaLN.bias"][0]
+        d.off_final_w, d.off_final_b = r["final.weight"][0], r["final.bias"][0]
+        d.off_layer0 = r["blocks.0.qkv.weight"][0]
+        d.layer_stride = L.load().uwu_dit_layer_param_stride(c.hidden, c.mlp_ratio)
+        if c.depth > 1:
+            assert r["blocks.1.qkv.weight"][0] - d.off_layer0 == d.layer_stride
+        d.pos = self.pos.data_ptr()
+        key = (B, d.dtype, self.flat.device)
+        if self._ws_key != key:
+            d.ws, d.ws_bytes = None, 0
+            need = L.load().uwu_dit_workspace_bytes(ctypes.byref(d))
+            self._ws = torch.empty(need, device=self.flat.device, dtype=torch.uint8)
+            self._ws_key = key
+        d.ws, d.ws_bytes = self._ws.data_ptr(), self._ws.numel()
+        return d
+
+    def _run_forward(self, noisy, t, cond):
+        B = noisy.shape[0]
+        d = self._descriptor(B)
+        out = torch.empty(B, self.cfg.out_channels, self.cfg.sample_size, self.cfg.sample_size, device=noisy.device,
+                          dtype=torch.float32)
+        L.call("uwu_dit_forward", ctypes.byref(d), L.ptr(noisy), L.ptr(t), L.ptr(cond), L.ptr(out), L.stream())
+        self._fwd_gen += 1
+        return out
+
+    def _run_backward(self, dout, cond):
+        if self.flat.grad is None:
+            self.flat.grad = torch.zeros_like(self.flat.data)
+        d = self._descriptor(dout.shape[0])
+        L.call("uwu_dit_backward", ctypes.byref(d), L.ptr(dout), L.stream())
+        if cond is not None:
+            L.call("uwu_dit_backward_cond", ctypes.byref(d), L.ptr(cond), L.stream())
+
+    # ------------------------------------------------------------------ denoiser slot
+    def forward(self, sample, timestep, encoder_hidden_states=None, encoder_attention_mask=None,
+                added_cond_kwargs=None, cross_attention_kwargs=None, **kw):
+        c = self.cfg
+        B = sample.shape[0]
+        noisy = sample.float().contiguous()
+        if not torch.is_tensor(timestep):
+            timestep = torch.tensor([timestep], device=sample.device)
+        t = timestep.to(device=sample.device, dtype=torch.float32).reshape(-1)
+        if t.numel() == 1 and B > 1:
+            t = t.expand(B)
+        t = t.contiguous()
+        cond = None
+        if c.cond_dim > 0:
+            pooled = (added_cond_kwargs or {}).get("text_embeds")
+            if pooled is None:
+                cond = torch.zeros(B, c.cond_dim, device=sample.device, dtype=torch.float32)
+            else:
+                cond = pooled.to(device=sample.device, dtype=torch.float32).contiguous()
+                if cond.shape != (B, c.cond_dim):
+                    raise ValueError(f"text_embeds must be [{B},{c.cond_dim}], got {tuple(cond.shape)}")
+        out = _DiTFn.apply(self.flat, self, noisy, t, cond)
+        return (out,)
+
+    @classmethod
+    def from_config(cls, config, **kw):
+        """``_target_: ...DiT.from_config`` with ``config: "DiT-S/2"`` (preset name) or a dict."""
+        init = kw.pop("init", "dit")
+        if isinstance(config, str):
+            if config not in PRESETS:
+                raise ValueError(f"unknown DiT preset {config!r}; known: {sorted(PRESETS)}")
+            cfg = dict(PRESETS[config])
+        else:
+            cfg = dict(config)
+        cfg.update(kw)
+        cfg.pop("subfolder", None)
+        return cls(DiTConfig(**cfg), init=init)

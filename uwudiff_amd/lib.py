@@ -24,7 +24,7 @@ class UwuError(RuntimeError):
 class DitDesc(ctypes.Structure):
     _fields_ = (
         [(n, c_int32) for n in ("B", "T", "D", "H", "L", "mlp_ratio", "in_ch", "out_ch", "patch", "img", "dtype",
-                                "cond_dim")]
+                                "cond_dim", "freq_dim")]
         + [("ln_eps", c_float), ("mod_total", c_int32)]
         + [("w", c_void_p), ("w32", c_void_p), ("g32", c_void_p)]
         + [(n, c_int64) for n in ("off_patch_w", "off_patch_b", "off_t_w1", "off_t_b1", "off_t_w2", "off_t_b2",
@@ -57,12 +57,15 @@ _SIGS = {
     "uwu_timestep_embedding": (c_int, [P, c_int, c_int, c_float, P, c_int, P]),
     "uwu_silu_fwd": (c_int, [P, P, c_int64, c_int, P]),
     "uwu_silu_bwd": (c_int, [P, P, P, c_int64, c_int, P]),
+    "uwu_add": (c_int, [P, P, P, c_int64, c_int, P]),
     "uwu_patchify": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "uwu_unpatchify": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     "uwu_add_pos": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "uwu_dit_workspace_bytes": (c_size_t, [ctypes.POINTER(DitDesc)]),
     "uwu_dit_forward": (c_int, [ctypes.POINTER(DitDesc), P, P, P, P, P]),
     "uwu_dit_backward": (c_int, [ctypes.POINTER(DitDesc), P, P]),
+    "uwu_dit_backward_cond": (c_int, [ctypes.POINTER(DitDesc), P, P]),
+    "uwu_dit_layer_param_stride": (c_int64, [c_int, c_int]),
 }
 
 _lib = None
