@@ -1,0 +1,441 @@
+// MFMA flash attention for gfx950 (bf16 operands, fp32 softmax/accumulate), head dim 64, self-attention.
+// Replaces F.scaled_dot_product_attention fwd/bwd (reference src/duwu/modules/rope_unet.py:151-153).
+//
+// All products use v_mfma_f32_32x32x16_bf16.  Lane maps (cdna_hip_programming.md section 3):
+//   A: lane (r=l&31, h=l>>5) holds A[row r][k=8h+j];  B: holds B[k=8h+j][col r];
+//   C/D: col = l&31, row = (i&3) + 8*(i>>2) + 4*h for register i in [0,16).
+// An accumulator tile X[row][col] is reused as the B operand of the next MFMA (contraction over X's ROW index)
+// by converting registers 8s..8s+7 to bf16: logical k-slot (h,j) then means row 16s + 8(j>>2) + 4h + (j&3),
+// so the OTHER operand's LDS image is stored with that row permutation (done by the transposing stager).
+//
+// forward  (4 waves x 32 query rows, KV tiles of 64 keys, online softmax):
+//   S^T[key][q] = K.Q^T  (K tile in LDS, Q fragments in registers)  -> softmax over registers + one lane-half
+//   exchange -> P^T stays in registers as the B operand of  O^T[d][q] += V^T[d][key].P^T[key][q].
+// backward (8 waves x 32 keys, whole key range <= 256 in one workgroup, query tiles of 64 rows):
+//   S[q][key] = Q.K^T, dP[q][key] = dO.V^T   (key on the lane; K/V fragments in registers)
+//   P = exp2(c*S - lse), dS = P*(dP - delta)
+//   dV^T[d][key] += dO^T[d][q].P[q][key],  dK^T[d][key] += Q^T[d][q].dS[q][key]   (accumulators as B operands)
+//   dQ[q][d] = dS[q][key].K[key][d]: dS goes through a wave-private LDS tile (the one transpose), the 8 waves'
+//   partial dQ tiles are summed with LDS float atomics and written once per query tile.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ int swz(int row, int chunk) {
+  return row * 128 + (((chunk ^ (row >> 1) ^ (row >> 4)) & 7) << 4);
+}
+__device__ __forceinline__ f32x16 mfma32(const uint4& a, const uint4& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a),
+                                                 *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
+}
+__device__ __forceinline__ uint4 pack8(const f32x16& x, int s) {
+  bf16x8 f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = (bf16_t)x[8 * s + j];
+  return *reinterpret_cast<uint4*>(&f);
+}
+__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+struct MArgs {
+  const bf16_t *q, *k, *v, *o, *dO;
+  bf16_t *out, *dq, *dk, *dv;
+  float* lse;
+  float* delta;
+  int B, T, H, ldq, ldk, ldv, ldo;
+  float scale;
+};
+
+// Row-major staging of a [64 rows][64 bf16] tile: `nthr` threads, 16 B per lane, swizzled image.
+// Transposed staging of the same tile into a [64 cols][64 rows-permuted] image: 256 threads, each 4 rows x 4 cols.
+struct TStage {
+  uint2 r[4];
+  __device__ __forceinline__ void load(const bf16_t* __restrict__ base, int ld, int row0, int t256) {
+    const int cg = t256 & 15, rq = t256 >> 4;  // cols 4cg..4cg+3, rows 4rq..4rq+3
+#pragma unroll
+    for (int kr = 0; kr < 4; ++kr)
+      r[kr] = *reinterpret_cast<const uint2*>(base + (int64_t)(row0 + 4 * rq + kr) * ld + 4 * cg);
+  }
+  __device__ __forceinline__ void store(char* __restrict__ lds, int t256) const {
+    const int cg = t256 & 15, rq = t256 >> 4;
+    const int chunk = 2 * (rq >> 2) + (rq & 1), sub = 8 * ((rq >> 1) & 1);
+    const unsigned* w0 = reinterpret_cast<const unsigned*>(&r[0]);
+    const unsigned* w1 = reinterpret_cast<const unsigned*>(&r[1]);
+    const unsigned* w2 = reinterpret_cast<const unsigned*>(&r[2]);
+    const unsigned* w3 = reinterpret_cast<const unsigned*>(&r[3]);
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) {
+      const int row = 4 * cg + ci;  // image row = source column
+      const unsigned sel = (ci & 1) ? 0x07060302u : 0x05040100u;
+      uint2 o;
+      o.x = __builtin_amdgcn_perm(w1[ci >> 1], w0[ci >> 1], sel);
+      o.y = __builtin_amdgcn_perm(w3[ci >> 1], w2[ci >> 1], sel);
+      *reinterpret_cast<uint2*>(lds + swz(row, chunk) + sub) = o;
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------- forward
+__global__ void __launch_bounds__(256, 2) attn_fwd_mfma(const MArgs a) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 16384];  // 2 stages x (K 8 KB | V^T 8 KB)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / a.H, hd = bh - b * a.H;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const bool active = q0 < a.T;  // wave-uniform
+  const bf16_t* qb = a.q + (int64_t)b * a.T * a.ldq + hd * 64;
+  const bf16_t* kb = a.k + (int64_t)b * a.T * a.ldk + hd * 64;
+  const bf16_t* vb = a.v + (int64_t)b * a.T * a.ldv + hd * 64;
+  const float c = a.scale * 1.4426950408889634f;
+
+  uint4 qf[4];
+  if (active) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      qf[s] = *reinterpret_cast<const uint4*>(qb + (int64_t)(q0 + r) * a.ldq + 16 * s + 8 * h);
+  }
+  f32x16 o[2];
+  o[0] = o[1] = f32x16{};
+  float m = -INFINITY, l = 0.f;
+
+  uint4 kreg[2];
+  TStage vreg;
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+      kreg[p] = *reinterpret_cast<const uint4*>(kb + (int64_t)(k0 + (tid >> 3) + 32 * p) * a.ldk + 8 * (tid & 7));
+    vreg.load(vb, a.ldv, k0, tid);
+  };
+  auto store_tile = [&](char* st) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) *reinterpret_cast<uint4*>(st + swz((tid >> 3) + 32 * p, tid & 7)) = kreg[p];
+    vreg.store(st + 8192, tid);
+  };
+
+  const int nt = a.T / 64;
+  load_tile(0);
+  store_tile(smem);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const char* Ks = smem + (t & 1) * 16384;
+    const char* Vs = Ks + 8192;
+    if (t + 1 < nt) load_tile((t + 1) * 64);
+    if (active) {
+      f32x16 s[2];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        s[kt] = f32x16{};
+#pragma unroll
+        for (int ss = 0; ss < 4; ++ss) {
+          uint4 kf = *reinterpret_cast<const uint4*>(Ks + swz(32 * kt + r, 2 * ss + h));
+          s[kt] = mfma32(kf, qf[ss], s[kt]);
+        }
+      }
+      float mx = s[0][0];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[kt][i]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mn = fmaxf(m, mx);
+      const float alpha = fexp2((m - mn) * c);
+      const float mc = mn * c;
+      float ls = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float p = fexp2(s[kt][i] * c - mc);
+          s[kt][i] = p;
+          ls += p;
+        }
+      l = l * alpha + ls;
+      m = mn;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const uint4 pf = pack8(s[kt], s2);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            uint4 vf = *reinterpret_cast<const uint4*>(Vs + swz(32 * dt + r, 2 * (2 * kt + s2) + h));
+            o[dt] = mfma32(vf, pf, o[dt]);
+          }
+        }
+    }
+    if (t + 1 < nt) store_tile(smem + ((t + 1) & 1) * 16384);
+    __syncthreads();
+  }
+  if (active) {
+    const float lt = l + __shfl_xor(l, 32, 64);
+    const float inv = 1.f / lt;
+    bf16_t* ob = a.out + (int64_t)b * a.T * a.ldo + hd * 64 + (int64_t)(q0 + r) * a.ldo;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int d0 = 32 * dt + 8 * g4 + 4 * h;
+        store4(ob + d0, f32x4{o[dt][4 * g4] * inv, o[dt][4 * g4 + 1] * inv, o[dt][4 * g4 + 2] * inv,
+                              o[dt][4 * g4 + 3] * inv});
+      }
+    if (h == 0) a.lse[((int64_t)b * a.H + hd) * a.T + q0 + r] = m * a.scale + __logf(lt);
+  }
+}
+
+// delta[b,h,t] = sum_d dO*O ; 8 lanes per head (16 B each), one wave covers 8 heads of one row
+__global__ void __launch_bounds__(256) attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dO,
+                                                         float* __restrict__ delta, int B, int T, int H, int ldo) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t rows = (int64_t)B * T;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const int b = (int)(row / T), t = (int)(row - (int64_t)b * T);
+    for (int h0 = 0; h0 < H; h0 += 8) {
+      const int hd = h0 + (lane >> 3);
+      float s = 0.f;
+      if (hd < H) {
+        const int64_t off = row * ldo + hd * 64 + 8 * (lane & 7);
+        bf16x8 ov = *reinterpret_cast<const bf16x8*>(o + off), gv = *reinterpret_cast<const bf16x8*>(dO + off);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += (float)ov[j] * (float)gv[j];
+      }
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 4, 64);
+      if (hd < H && (lane & 7) == 0) delta[((int64_t)b * H + hd) * T + t] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------- backward
+constexpr int BWD_STAGE = 32768;                  // Qs | dOs | QTs | dOTs (8 KB each)
+constexpr int BWD_OFF_LSE = 2 * BWD_STAGE;        // [2][64] lse*log2e, [2][64] delta
+constexpr int BWD_OFF_DS = BWD_OFF_LSE + 1024;    // 8 waves x 2 KB
+constexpr int BWD_OFF_DQ = BWD_OFF_DS + 8 * 2048;  // 2 x [64][64] fp32
+constexpr int BWD_LDS = BWD_OFF_DQ + 2 * 16384;
+
+__global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.x, b = bh / a.H, hd = bh - b * a.H;
+  const int k0 = wave * 32;
+  const bool active = k0 < a.T;  // wave-uniform
+  const bf16_t* qb = a.q + (int64_t)b * a.T * a.ldq + hd * 64;
+  const bf16_t* kb = a.k + (int64_t)b * a.T * a.ldk + hd * 64;
+  const bf16_t* vb = a.v + (int64_t)b * a.T * a.ldv + hd * 64;
+  const bf16_t* gb = a.dO + (int64_t)b * a.T * a.ldo + hd * 64;
+  const float* lseb = a.lse + ((int64_t)b * a.H + hd) * a.T;
+  const float* delb = a.delta + ((int64_t)b * a.H + hd) * a.T;
+  const float c = a.scale * 1.4426950408889634f;
+  float* dqacc = reinterpret_cast<float*>(smem + BWD_OFF_DQ);
+  char* dsw = smem + BWD_OFF_DS + wave * 2048;
+
+  // zero both dQ accumulators
+  for (int i = tid; i < 2 * 4096; i += 512) dqacc[i] = 0.f;
+
+  // per-wave static operands
+  uint4 kf[4], vf[4], ktf[2][2];
+  if (active) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      kf[s] = *reinterpret_cast<const uint4*>(kb + (int64_t)(k0 + r) * a.ldk + 16 * s + 8 * h);
+      vf[s] = *reinterpret_cast<const uint4*>(vb + (int64_t)(k0 + r) * a.ldv + 16 * s + 8 * h);
+    }
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = kb[(int64_t)(k0 + 16 * s + 8 * h + j) * a.ldk + 32 * dt + r];
+        ktf[dt][s] = *reinterpret_cast<uint4*>(&f);
+      }
+  }
+  f32x16 dkT[2], dvT[2];
+  dkT[0] = dkT[1] = dvT[0] = dvT[1] = f32x16{};
+
+  // staging registers: row-major Q and dO (one 16-B chunk each), transposed Q (threads 0-255) or dO (256-511)
+  uint4 qreg, greg;
+  TStage treg;
+  float lreg = 0.f, dreg = 0.f;
+  auto load_tile = [&](int q0) {
+    const int row = tid >> 3, ch = tid & 7;
+    qreg = *reinterpret_cast<const uint4*>(qb + (int64_t)(q0 + row) * a.ldq + 8 * ch);
+    greg = *reinterpret_cast<const uint4*>(gb + (int64_t)(q0 + row) * a.ldo + 8 * ch);
+    if (tid < 256) treg.load(qb, a.ldq, q0, tid); else treg.load(gb, a.ldo, q0, tid - 256);
+    if (tid < 64) lreg = lseb[q0 + tid] * 1.4426950408889634f;
+    else if (tid < 128) dreg = delb[q0 + tid - 64];
+  };
+  auto store_tile = [&](int stage) {
+    char* st = smem + stage * BWD_STAGE;
+    const int row = tid >> 3, ch = tid & 7;
+    *reinterpret_cast<uint4*>(st + swz(row, ch)) = qreg;
+    *reinterpret_cast<uint4*>(st + 8192 + swz(row, ch)) = greg;
+    if (tid < 256) treg.store(st + 16384, tid); else treg.store(st + 24576, tid - 256);
+    float* ls = reinterpret_cast<float*>(smem + BWD_OFF_LSE) + stage * 64;
+    float* dl = reinterpret_cast<float*>(smem + BWD_OFF_LSE + 512) + stage * 64;
+    if (tid < 64) ls[tid] = lreg;
+    else if (tid < 128) dl[tid - 64] = dreg;
+  };
+
+  const int nt = a.T / 64;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int stage = t & 1;
+    const char* Qs = smem + stage * BWD_STAGE;
+    const char* Gs = Qs + 8192;
+    const char* QTs = Qs + 16384;
+    const char* GTs = Qs + 24576;
+    const float* ls = reinterpret_cast<const float*>(smem + BWD_OFF_LSE) + stage * 64;
+    const float* dl = reinterpret_cast<const float*>(smem + BWD_OFF_LSE + 512) + stage * 64;
+    float* acc = dqacc + stage * 4096;
+    if (t + 1 < nt) load_tile((t + 1) * 64);
+    if (active) {
+#pragma unroll 1
+      for (int sub = 0; sub < 2; ++sub) {
+        f32x16 S = {}, dP = {};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          uint4 qa = *reinterpret_cast<const uint4*>(Qs + swz(32 * sub + r, 2 * s + h));
+          uint4 ga = *reinterpret_cast<const uint4*>(Gs + swz(32 * sub + r, 2 * s + h));
+          S = mfma32(qa, kf[s], S);
+          dP = mfma32(ga, vf[s], dP);
+        }
+        // P and dS in place (rows = q in registers, cols = key on lanes)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x4 l4 = load4(ls + 32 * sub + 8 * g4 + 4 * h);
+          const f32x4 d4 = load4(dl + 32 * sub + 8 * g4 + 4 * h);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int i = 4 * g4 + e;
+            const float p = fexp2(S[i] * c - l4[e]);
+            S[i] = p;
+            dP[i] = p * (dP[i] - d4[e]);
+          }
+        }
+        // dS -> wave-private LDS tile [32 q][32 keys] bf16 (64-B rows, 16-B chunk XOR (q>>2)&3)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int qrow = (i & 3) + 8 * (i >> 2) + 4 * h;
+          *reinterpret_cast<bf16_t*>(dsw + qrow * 64 + ((((r >> 3) ^ (qrow >> 2)) & 3) << 4) + (r & 7) * 2) =
+              (bf16_t)dP[i];
+        }
+        // same-wave LDS write -> read: LDS executes a wave's accesses in order; the asm is the compiler-level
+        // barrier (the 2-byte stores and 16-byte loads have different types, TBAA must not reorder them)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const uint4 pf = pack8(S, s2), dsf = pack8(dP, s2);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            uint4 gt = *reinterpret_cast<const uint4*>(GTs + swz(32 * dt + r, 2 * (2 * sub + s2) + h));
+            uint4 qt = *reinterpret_cast<const uint4*>(QTs + swz(32 * dt + r, 2 * (2 * sub + s2) + h));
+            dvT[dt] = mfma32(gt, pf, dvT[dt]);
+            dkT[dt] = mfma32(qt, dsf, dkT[dt]);
+          }
+        }
+        // dQ partial = dS . K over this wave's 32 keys (A operand: dS rows from the private tile)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          f32x16 dq = {};
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            uint4 da = *reinterpret_cast<const uint4*>(dsw + r * 64 + ((((2 * s2 + h) ^ (r >> 2)) & 3) << 4));
+            dq = mfma32(da, ktf[dt][s2], dq);
+          }
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int qrow = 32 * sub + (i & 3) + 8 * (i >> 2) + 4 * h;
+            atomicAdd(acc + qrow * 64 + 32 * dt + r, dq[i]);
+          }
+        }
+        asm volatile("" ::: "memory");  // the next sub-tile rewrites the private dS tile after these reads
+      }
+    }
+    if (t + 1 < nt) store_tile((t + 1) & 1);
+    __syncthreads();
+    // write the finished dQ tile (all 512 threads: 64 rows x 64 d, 8 values each) and re-zero its accumulator
+    {
+      const int row = tid >> 3, d0 = 8 * (tid & 7);
+      float* ap = acc + row * 64 + d0;
+      f32x4 v0 = load4(ap), v1 = load4(ap + 4);
+      bf16x8 ov;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        ov[e] = (bf16_t)(v0[e] * a.scale);
+        ov[4 + e] = (bf16_t)(v1[e] * a.scale);
+      }
+      *reinterpret_cast<bf16x8*>(a.dq + (int64_t)b * a.T * a.ldq + hd * 64 + (int64_t)(t * 64 + row) * a.ldq + d0) = ov;
+      store4(ap, f32x4{0.f, 0.f, 0.f, 0.f});
+      store4(ap + 4, f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+  }
+  if (active) {
+    bf16_t* dkb = a.dk + (int64_t)b * a.T * a.ldk + hd * 64 + (int64_t)(k0 + r) * a.ldk;
+    bf16_t* dvb = a.dv + (int64_t)b * a.T * a.ldv + hd * 64 + (int64_t)(k0 + r) * a.ldv;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int d0 = 32 * dt + 8 * g4 + 4 * h;
+        store4(dkb + d0, f32x4{dkT[dt][4 * g4] * a.scale, dkT[dt][4 * g4 + 1] * a.scale,
+                               dkT[dt][4 * g4 + 2] * a.scale, dkT[dt][4 * g4 + 3] * a.scale});
+        store4(dvb + d0, f32x4{dvT[dt][4 * g4], dvT[dt][4 * g4 + 1], dvT[dt][4 * g4 + 2], dvT[dt][4 * g4 + 3]});
+      }
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------- host side
+bool uwu_attn_mfma_fwd_ok(int Tq, int Tk, int d, int ldq, int ldk, int ldv, int ldo) {
+  return d == 64 && Tq == Tk && Tq % 64 == 0 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0;
+}
+bool uwu_attn_mfma_bwd_ok(int Tq, int Tk, int d, int ldq, int ldk, int ldv, int ldo) {
+  return uwu_attn_mfma_fwd_ok(Tq, Tk, d, ldq, ldk, ldv, ldo) && Tq <= 256;
+}
+
+int uwu_attn_mfma_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int T, int H, int ldq,
+                      int ldk, int ldv, int ldo, float scale, hipStream_t st) {
+  UWU_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0,
+                "attention(mfma): q/k/v/o must be 16-byte aligned");
+  MArgs a{};
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)o; a.lse = lse;
+  a.B = B; a.T = T; a.H = H; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.scale = scale;
+  hipLaunchKernelGGL(attn_fwd_mfma, dim3((T + 127) / 128, B * H), dim3(256), 0, st, a);
+  UWU_LAUNCH_CHECK("attention_fwd(mfma)");
+  return UWU_OK;
+}
+
+int uwu_attn_mfma_bwd(const void* q, const void* k, const void* v, const void* o, const void* dO, const float* lse,
+                      float* delta, void* dq, void* dk, void* dv, int B, int T, int H, int ldq, int ldk, int ldv,
+                      int ldo, float scale, hipStream_t st) {
+  UWU_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)dO | (uintptr_t)dq |
+                  (uintptr_t)dk | (uintptr_t)dv) & 15) == 0,
+                "attention_bwd(mfma): tensors must be 16-byte aligned");
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              BWD_LDS);
+    attr_done = true;
+  }
+  int grid = (int)(((int64_t)B * T + 3) / 4);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)o, (const bf16_t*)dO, delta, B, T,
+                     H, ldo);
+  UWU_LAUNCH_CHECK("attention_delta");
+  MArgs a{};
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o;
+  a.dO = (const bf16_t*)dO; a.lse = const_cast<float*>(lse); a.delta = delta;
+  a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
+  a.B = B; a.T = T; a.H = H; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.scale = scale;
+  hipLaunchKernelGGL(attn_bwd_mfma, dim3(B * H), dim3(512), BWD_LDS, st, a);
+  UWU_LAUNCH_CHECK("attention_bwd(mfma)");
+  return UWU_OK;
+}

@@ -6,6 +6,8 @@
 // Q/dO) tiles of 32 rows are staged in LDS as fp32 and read as wave-broadcasts.
 // Semantics: F.scaled_dot_product_attention(q,k,v, dropout_p=0, is_causal=False) -- reference
 // src/duwu/modules/rope_unet.py:151-153; flash-style backward recomputes P from the saved log-sum-exp.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -300,6 +302,23 @@ static int uwu_attention_simple(const AttnArgs& a, int dtype, bool bwd, hipStrea
   return UWU_EINVAL;
 }
 
+// MFMA kernels (attention_mfma.hip)
+bool uwu_attn_mfma_fwd_ok(int Tq, int Tk, int d, int ldq, int ldk, int ldv, int ldo);
+bool uwu_attn_mfma_bwd_ok(int Tq, int Tk, int d, int ldq, int ldk, int ldv, int ldo);
+int uwu_attn_mfma_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int T, int H, int ldq,
+                      int ldk, int ldv, int ldo, float scale, hipStream_t st);
+int uwu_attn_mfma_bwd(const void* q, const void* k, const void* v, const void* o, const void* dO, const float* lse,
+                      float* delta, void* dq, void* dk, void* dv, int B, int T, int H, int ldq, int ldk, int ldv,
+                      int ldo, float scale, hipStream_t st);
+static bool force_simple() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("UWU_ATTN_SIMPLE");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v == 1;
+}
+
 static int check_common(const void* q, const void* k, const void* v, int B, int Tq, int Tk, int H, int d, int ldq,
                         int ldk, int ldv, int ldo, int dtype) {
   UWU_CHECK_ARG(q && k && v, "attention: null pointer");
@@ -319,6 +338,9 @@ extern "C" int uwu_attention_fwd(const void* q, const void* k, const void* v, vo
   int rc = check_common(q, k, v, B, Tq, Tk, H, d, ldq, ldk, ldv, ldo, dtype);
   if (rc) return rc;
   UWU_CHECK_ARG(o && lse, "attention_fwd: null output");
+  if (dtype == UWU_BF16 && !force_simple() && uwu_attn_mfma_fwd_ok(Tq, Tk, d, ldq, ldk, ldv, ldo) &&
+      (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0)
+    return uwu_attn_mfma_fwd(q, k, v, o, lse, B, Tq, H, ldq, ldk, ldv, ldo, scale, (hipStream_t)stream);
   AttnArgs a{};
   a.q = q; a.k = k; a.v = v; a.out = o; a.lse = lse;
   a.B = B; a.Tq = Tq; a.Tk = Tk; a.H = H; a.d = d; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
@@ -333,6 +355,11 @@ extern "C" int uwu_attention_bwd(const void* q, const void* k, const void* v, co
   int rc = check_common(q, k, v, B, Tq, Tk, H, d, ldq, ldk, ldv, ldo, dtype);
   if (rc) return rc;
   UWU_CHECK_ARG(o && dO && lse && delta && dq && dk && dv, "attention_bwd: null pointer");
+  if (dtype == UWU_BF16 && !force_simple() && uwu_attn_mfma_bwd_ok(Tq, Tk, d, ldq, ldk, ldv, ldo) &&
+      (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)dO | (uintptr_t)dq | (uintptr_t)dk |
+        (uintptr_t)dv) & 15) == 0)
+    return uwu_attn_mfma_bwd(q, k, v, o, dO, lse, delta, dq, dk, dv, B, Tq, H, ldq, ldk, ldv, ldo, scale,
+                             (hipStream_t)stream);
   AttnArgs a{};
   a.q = q; a.k = k; a.v = v; a.o = o; a.dO = dO; a.lse = const_cast<float*>(lse); a.delta = delta; a.dq = dq; a.dk = dk; a.dv = dv;
   a.B = B; a.Tq = Tq; a.Tk = Tk; a.H = H; a.d = d; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;

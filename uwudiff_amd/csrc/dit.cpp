@@ -135,6 +135,20 @@ int lin_dgrad(const void* dY, const void* W, void* dX, const void* aux, int M, i
   return uwu_gemm(dY, W, dX, nullptr, nullptr, aux, M, K, N, N, K, K, K, 0, 1, dt, dt,
                   aux ? UWU_EPI_DGELU : UWU_EPI_NONE, 1, st);
 }
+// dX[M,K] = dY[M,N] . W[N,K] for a LONG reduction N and few rows M (the batched adaLN linear: N = L*6*D+2*D):
+// split the reduction over workgroups and accumulate with fp32 atomics into a zeroed dX.
+int lin_dgrad_splitk(const void* dY, const void* W, float* dX, int M, int N, int K, void* st) {
+  if (hipMemsetAsync(dX, 0, (size_t)M * K * sizeof(float), (hipStream_t)st) != hipSuccess) {
+    uwu_set_error("dgrad_splitk: memset failed");
+    return UWU_ELAUNCH;
+  }
+  const int tiles = ((M + 127) / 128) * ((K + 127) / 128);
+  const int ktiles = (N + 31) / 32;
+  int split = (512 + tiles - 1) / tiles;
+  if (split > ktiles) split = ktiles;
+  return uwu_gemm(dY, W, dX, nullptr, nullptr, nullptr, M, K, N, N, K, K, 0, 0, 1, UWU_F32, UWU_F32, UWU_EPI_ACCUM, split,
+                  st);
+}
 // dW[N,K] += dY[M,N]^T . X[M,K]   (fp32 atomics, split over the token dimension)
 int lin_wgrad(const void* dY, const void* X, float* dW, int M, int N, int K, int dt, void* st) {
   const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
@@ -366,7 +380,7 @@ extern "C" int uwu_dit_backward(const uwu_dit_desc* dp, const float* dout, void*
   // ---- conditioning path (fp32)
   RUN(lin_wgrad(dmod, P.at(L.sc), g + d.off_mod_w, B, ML, D, UWU_F32, st));
   RUN(uwu_colsum(dmod, UWU_F32, B, ML, ML, g + d.off_mod_b, 1, st));
-  RUN(lin_dgrad(dmod, w32 + d.off_mod_w, P.at(L.dsc), nullptr, B, ML, D, UWU_F32, st));
+  RUN(lin_dgrad_splitk(dmod, w32 + d.off_mod_w, P.at<float>(L.dsc), B, ML, D, st));
   const void* cptr = d.cond_dim > 0 ? P.at(L.c) : P.at(L.temb);
   RUN(uwu_silu_bwd(cptr, P.at(L.dsc), P.at(L.dc), (int64_t)B * D, UWU_F32, st));
   if (d.cond_dim > 0) {

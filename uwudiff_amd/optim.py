@@ -1,0 +1,65 @@
+"""Fused flat-buffer AdamW + global-norm clip on the HIP kernels (csrc/optimizer.hip).
+
+Mirrors ``torch.optim.AdamW`` single-tensor semantics (the reference instantiates ``torch.optim.AdamW`` from YAML,
+reference src/duwu/trainer/trainer.py:52-74, configs/demo_training_latent.yaml:30-39) and Lightning's
+``gradient_clip_val`` (global L2 norm, demo_training.yaml:12).  One launch per flat parameter buffer; the bf16
+shadow of the parameters (MFMA operands) is refreshed by the same kernel.
+"""
+import math
+
+import torch
+
+from . import lib as L
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self._norm_ws = {}
+
+    def _ws(self, device):
+        w = self._norm_ws.get(device)
+        if w is None:
+            w = (torch.empty(1024, device=device, dtype=torch.float32), torch.ones(2, device=device, dtype=torch.float32))
+            self._norm_ws[device] = w
+        return w
+
+    @torch.no_grad()
+    def grad_norm_clip(self, max_norm, pre_scale=1.0):
+        """Launches the global-norm reduction; returns the device tensor [sumsq, clip_coef] (no host sync).
+        Only single-buffer models (one flat parameter) are clipped in one launch."""
+        ps = [p for g in self.param_groups for p in g["params"] if p.grad is not None]
+        if len(ps) != 1:
+            raise NotImplementedError("grad_norm_clip expects one flat parameter buffer")
+        p = ps[0]
+        part, out = self._ws(p.device)
+        L.call("uwu_grad_sqnorm_clip", L.ptr(p.grad), p.numel(), float(pre_scale), float(max_norm or 0.0), L.ptr(part),
+               L.ptr(out), L.stream())
+        return out
+
+    @torch.no_grad()
+    def step(self, closure=None, clip=None, pre_scale=1.0):
+        loss = closure() if closure is not None else None
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p.data)
+                    st["exp_avg_sq"] = torch.zeros_like(p.data)
+                st["step"] += 1
+                shadow = getattr(p, "_uwu_bf16_shadow", None)
+                L.call("uwu_adamw_step", L.ptr(p.data), L.ptr(p.grad), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]),
+                       L.ptr(shadow) if shadow is not None and shadow.numel() == p.numel() else None, p.numel(),
+                       float(group["lr"]), b1, b2, group["eps"], group["weight_decay"], st["step"], float(pre_scale),
+                       L.ptr(clip) if clip is not None else None, L.stream())
+        return loss
+
+
+def cosine_lr(base_lr, step, T_max, eta_min):
+    """Closed form of torch.optim.lr_scheduler.CosineAnnealingLR (trainer.py:111-115 defaults)."""
+    return eta_min + (base_lr - eta_min) * (1 + math.cos(math.pi * step / T_max)) / 2
