@@ -15,8 +15,10 @@
 //   S[q][key] = Q.K^T, dP[q][key] = dO.V^T   (key on the lane; K/V fragments in registers)
 //   P = exp2(c*S - lse), dS = P*(dP - delta)
 //   dV^T[d][key] += dO^T[d][q].P[q][key],  dK^T[d][key] += Q^T[d][q].dS[q][key]   (accumulators as B operands)
-//   dQ[q][d] = dS[q][key].K[key][d]: dS goes through a wave-private LDS tile (the one transpose), the 8 waves'
-//   partial dQ tiles are summed with LDS float atomics and written once per query tile.
+//   dQ contracts over the key = the LANE index of dS, so dS takes the one trip through LDS: every wave writes
+//   its 32-key slice into a shared [q][key] bf16 image, then each wave computes two 16x16 blocks of
+//   dQ^T[d][q] = K^T[d][key].dS^T[key][q] over ALL keys with v_mfma_f32_16x16x32_bf16 against a resident K^T
+//   image -- no cross-wave reduction (LDS float atomics measured 5x slower than the whole rest of the kernel).
 #include "common.h"
 
 namespace {
@@ -210,11 +212,15 @@ __global__ void __launch_bounds__(256) attn_delta_kernel(const bf16_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------- backward
-constexpr int BWD_STAGE = 32768;                  // Qs | dOs | QTs | dOTs (8 KB each)
-constexpr int BWD_OFF_LSE = 2 * BWD_STAGE;        // [2][64] lse*log2e, [2][64] delta
-constexpr int BWD_OFF_DS = BWD_OFF_LSE + 1024;    // 8 waves x 2 KB
-constexpr int BWD_OFF_DQ = BWD_OFF_DS + 8 * 2048;  // 2 x [64][64] fp32
-constexpr int BWD_LDS = BWD_OFF_DQ + 2 * 16384;
+constexpr int BWD_STAGE = 32768;                    // Qs | dOs | QTs | dOTs (8 KB each)
+constexpr int BWD_OFF_LSE = 2 * BWD_STAGE;          // [2][64] lse*log2e, [2][64] delta
+constexpr int BWD_OFF_DS = BWD_OFF_LSE + 1024;      // dS image  [64 q][256 keys] bf16 (512-B rows)
+constexpr int BWD_OFF_KT = BWD_OFF_DS + 32768;      // K^T image [64 d][256 keys] bf16 (512-B rows)
+constexpr int BWD_LDS = BWD_OFF_KT + 32768;
+
+// 512-byte rows (256 bf16): 16-B chunk c of row r lives at chunk c ^ (r & 15) -> the 16x16x32 fragment reads
+// (16 lanes = 16 consecutive rows, same chunk) hit 16 distinct slots of the 256-B bank row.
+__device__ __forceinline__ int off512(int row, int chunk) { return row * 512 + ((chunk ^ (row & 15)) << 4); }
 
 __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -230,29 +236,39 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
   const float* lseb = a.lse + ((int64_t)b * a.H + hd) * a.T;
   const float* delb = a.delta + ((int64_t)b * a.H + hd) * a.T;
   const float c = a.scale * 1.4426950408889634f;
-  float* dqacc = reinterpret_cast<float*>(smem + BWD_OFF_DQ);
-  char* dsw = smem + BWD_OFF_DS + wave * 2048;
+  char* dsimg = smem + BWD_OFF_DS;
+  char* ktimg = smem + BWD_OFF_KT;
 
-  // zero both dQ accumulators
-  for (int i = tid; i < 2 * 4096; i += 512) dqacc[i] = 0.f;
+  // K^T image for the dQ product: [d][key], natural key order, built once (4 keys x 4 d per thread-step)
+  for (int kt64 = tid >> 8; kt64 * 64 < a.T; kt64 += 2) {
+    TStage ks;
+    const int t256 = tid & 255;
+    ks.load(kb, a.ldk, kt64 * 64, t256);
+    const int cg = t256 & 15, rq = t256 >> 4;
+    const int key = kt64 * 64 + 4 * rq;
+    const unsigned* w0 = reinterpret_cast<const unsigned*>(&ks.r[0]);
+    const unsigned* w1 = reinterpret_cast<const unsigned*>(&ks.r[1]);
+    const unsigned* w2 = reinterpret_cast<const unsigned*>(&ks.r[2]);
+    const unsigned* w3 = reinterpret_cast<const unsigned*>(&ks.r[3]);
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) {
+      const int row = 4 * cg + ci;
+      const unsigned sel = (ci & 1) ? 0x07060302u : 0x05040100u;
+      uint2 o;
+      o.x = __builtin_amdgcn_perm(w1[ci >> 1], w0[ci >> 1], sel);
+      o.y = __builtin_amdgcn_perm(w3[ci >> 1], w2[ci >> 1], sel);
+      *reinterpret_cast<uint2*>(ktimg + off512(row, key >> 3) + 8 * ((key >> 2) & 1)) = o;
+    }
+  }
 
-  // per-wave static operands
-  uint4 kf[4], vf[4], ktf[2][2];
+  // per-wave static operands: K and V rows of this wave's 32 keys (B operands of S and dP)
+  uint4 kf[4], vf[4];
   if (active) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       kf[s] = *reinterpret_cast<const uint4*>(kb + (int64_t)(k0 + r) * a.ldk + 16 * s + 8 * h);
       vf[s] = *reinterpret_cast<const uint4*>(vb + (int64_t)(k0 + r) * a.ldv + 16 * s + 8 * h);
     }
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        bf16x8 f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = kb[(int64_t)(k0 + 16 * s + 8 * h + j) * a.ldk + 32 * dt + r];
-        ktf[dt][s] = *reinterpret_cast<uint4*>(&f);
-      }
   }
   f32x16 dkT[2], dvT[2];
   dkT[0] = dkT[1] = dvT[0] = dvT[1] = f32x16{};
@@ -282,6 +298,8 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
   };
 
   const int nt = a.T / 64;
+  const int nk32 = a.T / 32;
+  const int fr = lane & 15, fq = lane >> 4;
   load_tile(0);
   store_tile(0);
   __syncthreads();
@@ -293,8 +311,8 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
     const char* GTs = Qs + 24576;
     const float* ls = reinterpret_cast<const float*>(smem + BWD_OFF_LSE) + stage * 64;
     const float* dl = reinterpret_cast<const float*>(smem + BWD_OFF_LSE + 512) + stage * 64;
-    float* acc = dqacc + stage * 4096;
     if (t + 1 < nt) load_tile((t + 1) * 64);
+    // ---- phase 1: this wave's 32 keys against the 64 staged query rows
     if (active) {
 #pragma unroll 1
       for (int sub = 0; sub < 2; ++sub) {
@@ -319,16 +337,15 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
             dP[i] = p * (dP[i] - d4[e]);
           }
         }
-        // dS -> wave-private LDS tile [32 q][32 keys] bf16 (64-B rows, 16-B chunk XOR (q>>2)&3)
+        // dS -> shared image [q][key] (the one transpose: dQ contracts over the lane index)
+        {
+          const int key = k0 + r;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int qrow = (i & 3) + 8 * (i >> 2) + 4 * h;
-          *reinterpret_cast<bf16_t*>(dsw + qrow * 64 + ((((r >> 3) ^ (qrow >> 2)) & 3) << 4) + (r & 7) * 2) =
-              (bf16_t)dP[i];
+          for (int i = 0; i < 16; ++i) {
+            const int qrow = 32 * sub + (i & 3) + 8 * (i >> 2) + 4 * h;
+            *reinterpret_cast<bf16_t*>(dsimg + off512(qrow, key >> 3) + (key & 7) * 2) = (bf16_t)dP[i];
+          }
         }
-        // same-wave LDS write -> read: LDS executes a wave's accesses in order; the asm is the compiler-level
-        // barrier (the 2-byte stores and 16-byte loads have different types, TBAA must not reorder them)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           const uint4 pf = pack8(S, s2), dsf = pack8(dP, s2);
@@ -340,41 +357,29 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
             dkT[dt] = mfma32(qt, dsf, dkT[dt]);
           }
         }
-        // dQ partial = dS . K over this wave's 32 keys (A operand: dS rows from the private tile)
+      }
+    }
+    __syncthreads();  // dS image complete for all keys
+    // ---- phase 2: dQ^T[d][q] = K^T[d][key] . dS^T[key][q]; wave w owns q-block (w&3) and d-blocks 2(w>>2), +1
+    {
+      const int qblk = wave & 3;
+      bf16_t* dqrow = a.dq + (int64_t)b * a.T * a.ldq + hd * 64 + (int64_t)(t * 64 + 16 * qblk + fr) * a.ldq;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          f32x16 dq = {};
-#pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
-            uint4 da = *reinterpret_cast<const uint4*>(dsw + r * 64 + ((((2 * s2 + h) ^ (r >> 2)) & 3) << 4));
-            dq = mfma32(da, ktf[dt][s2], dq);
-          }
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int qrow = 32 * sub + (i & 3) + 8 * (i >> 2) + 4 * h;
-            atomicAdd(acc + qrow * 64 + 32 * dt + r, dq[i]);
-          }
+      for (int dbi = 0; dbi < 2; ++dbi) {
+        const int db = 2 * (wave >> 2) + dbi;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int kk = 0; kk < nk32; ++kk) {
+          uint4 ka = *reinterpret_cast<const uint4*>(ktimg + off512(16 * db + fr, 4 * kk + fq));
+          uint4 da = *reinterpret_cast<const uint4*>(dsimg + off512(16 * qblk + fr, 4 * kk + fq));
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&ka),
+                                                        *reinterpret_cast<const bf16x8*>(&da), acc, 0, 0, 0);
         }
-        asm volatile("" ::: "memory");  // the next sub-tile rewrites the private dS tile after these reads
+        // D[row = d = 16db + 4fq + reg][col = q = fr]: 4 consecutive d of one query row per lane
+        store4(dqrow + 16 * db + 4 * fq, acc * a.scale);
       }
     }
     if (t + 1 < nt) store_tile((t + 1) & 1);
-    __syncthreads();
-    // write the finished dQ tile (all 512 threads: 64 rows x 64 d, 8 values each) and re-zero its accumulator
-    {
-      const int row = tid >> 3, d0 = 8 * (tid & 7);
-      float* ap = acc + row * 64 + d0;
-      f32x4 v0 = load4(ap), v1 = load4(ap + 4);
-      bf16x8 ov;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        ov[e] = (bf16_t)(v0[e] * a.scale);
-        ov[4 + e] = (bf16_t)(v1[e] * a.scale);
-      }
-      *reinterpret_cast<bf16x8*>(a.dq + (int64_t)b * a.T * a.ldq + hd * 64 + (int64_t)(t * 64 + row) * a.ldq + d0) = ov;
-      store4(ap, f32x4{0.f, 0.f, 0.f, 0.f});
-      store4(ap + 4, f32x4{0.f, 0.f, 0.f, 0.f});
-    }
+    __syncthreads();  // dS image free again; next stage visible
   }
   if (active) {
     bf16_t* dkb = a.dk + (int64_t)b * a.T * a.ldk + hd * 64 + (int64_t)(k0 + r) * a.ldk;
