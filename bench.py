@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Headline benchmark: data-parallel DiT-S/2 training step on synthetic 4x32x32 latents (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W [--batch B]
+
+One process per GPU (RANK/LOCAL_RANK/WORLD_SIZE from torch.distributed.run).  A step = sample (t, eps) +
+q-sample -> DiT forward -> v/eps MSE loss -> backward -> gradient all-reduce (RCCL) -> AdamW + cosine LR, on
+inputs already resident in HBM.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MODEL = "DiT-S/2"
+STEP_GFLOP_PER_IMG = 36.3   # BASELINE.md section 2 (3 x forward, no recompute)
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def cpu_baseline(batch=16, warm=1, iters=3):
+    """The oracle (this build's fp32 PyTorch restatement of the same model + loss) timed on the host cores."""
+    from oracle import loss as OL
+    from oracle.dit import DiTOracle
+    from oracle.scheduler import EulerDiscreteScheduler
+
+    torch.manual_seed(0)
+    # threads = the CPUs this process may actually run on (the GPU box gives 16 per GPU; os.cpu_count() reports
+    # the whole host and oversubscribing it stalls for minutes)
+    try:
+        n_thr = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n_thr = os.cpu_count() or 1
+    n_thr = max(1, min(n_thr, 16))
+    torch.set_num_threads(n_thr)
+    print(f"[bench] cpu_baseline: oracle DiT-S/2 fp32 on {n_thr} threads ...", file=sys.stderr, flush=True)
+    model = DiTOracle(depth=12, hidden=384, heads=6, cond_dim=1280)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_(torch.randn_like(p) * 0.02)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-6, weight_decay=0.01)
+    sched = EulerDiscreteScheduler.sdxl()
+    x = torch.randn(batch, 4, 32, 32)
+    pooled = torch.randn(batch, 1280)
+
+    def step():
+        noise = torch.randn_like(x)
+        t = torch.randint(0, 1000, (batch,))
+        noisy = OL.q_sample(x, noise, OL.sigmas_for_timesteps(sched, t))
+        out = model(noisy, t, added_cond_kwargs={"text_embeds": pooled})[0]
+        loss = ((out - noise) ** 2).flatten(1).mean(1).mean()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+
+    for _ in range(warm):
+        step()
+    ts = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        step()
+        ts.append(time.perf_counter() - t0)
+        print(f"[bench] cpu step {ts[-1]:.2f} s", file=sys.stderr, flush=True)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return {"value": round(batch / med, 2), "unit": "images/s", "cores": n_thr, "kind": "port",
+            "sample": f"oracle DiT-S/2 fp32 CPU, batch {batch}, median of {iters} steps (fwd+bwd+AdamW) after {warm} warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--clip", type=float, default=0.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from uwudiff_amd import lib as L
+    from uwudiff_amd.dit import DiT
+    from uwudiff_amd.gradsync import FlatGradSync
+    from uwudiff_amd.objective import DiffusionLoss
+    from uwudiff_amd.optim import FusedAdamW, cosine_lr
+    from uwudiff_amd.scheduler import EulerDiscreteScheduler
+
+    B = args.batch
+    torch.manual_seed(1215 + rank)  # configs/demo_training_latent.yaml:1 + test_train.py:69 (seed + rank)
+    # random (non-zero) weights everywhere: zero-initialised gates would make whole branches numerically dead
+    model = DiT.from_config(MODEL, cond_dim=1280, init="random", compute_dtype=args.dtype).to(dev)
+    if world > 1:  # identical replicas: broadcast rank 0's parameters
+        dist.broadcast(model.flat.data, src=0)
+        model.refresh_shadow()
+    loss_fn = DiffusionLoss(EulerDiscreteScheduler.from_pretrained("stabilityai/stable-diffusion-xl-base-1.0",
+                                                                   subfolder="scheduler"))
+    opt = FusedAdamW(model.parameters(), lr=1e-6, weight_decay=0.01, betas=(0.9, 0.999))
+    sync = FlatGradSync(world)
+    pool_n = max(4096, 2 * B)
+    pool = torch.randn(pool_n, 4, 32, 32, device=dev)          # synthetic latents resident in HBM
+    pooled = torch.randn(pool_n, 1280, device=dev)             # synthetic pooled-text conditioning
+    model.flat.grad = torch.zeros_like(model.flat.data)
+    step_no = [0]
+
+    def step():
+        i = step_no[0]
+        off = (i * B) % (pool_n - B + 1)
+        x, c = pool[off:off + B], pooled[off:off + B]
+        model.flat.grad.zero_()
+        loss, _ = loss_fn(x, model, added_cond_kwargs={"text_embeds": c})
+        loss.backward()
+        chunks = sync.all_reduce(model.flat.grad)
+        opt.param_groups[0]["lr"] = cosine_lr(1e-6, i, 100_000, 1e-7)
+        if args.clip > 0:
+            sync.wait_all()
+            clip = opt.grad_norm_clip(args.clip, pre_scale=sync.pre_scale)
+            opt.step(clip=clip, pre_scale=sync.pre_scale)
+        else:
+            opt.step(pre_scale=sync.pre_scale, chunks=chunks, before_chunk=sync.wait_chunk)
+        step_no[0] += 1
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if rank == 0:
+        print(f"[bench] {MODEL} {args.dtype} per-GPU batch {B} x {world} GPU(s): warm-up {args.warmup}, timing {args.steps} steps",
+              file=sys.stderr, flush=True)
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = te.item()
+    final_loss = float(loss.detach())
+    if rank == 0:
+        print(f"[bench] timed region done: {elapsed / args.steps * 1e3:.3f} ms/step", file=sys.stderr, flush=True)
+
+    # ---- roofline of the dominant kernel (bf16 MFMA GEMM family): HIP events around every GEMM launch on the
+    # launch stream, over a replay of the same steps (instrumentation kept out of the throughput window)
+    roof = None
+    if rank == 0:
+        lib = L.load()
+        n_prof = min(5, max(1, args.steps))
+        L.check(lib.uwu_gemm_prof_enable(1), "prof_enable")
+        for _ in range(n_prof):
+            step()
+        torch.cuda.synchronize()
+        L.check(lib.uwu_gemm_prof_enable(0), "prof_disable")
+        ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+        kind = 0 if args.dtype == "bf16" else 1
+        L.check(lib.uwu_gemm_prof_collect(kind, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)), "prof_collect")
+        if n.value:
+            ach = fl.value / (ms.value * 1e-3) / 1e12
+            peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_BF16_TFLOPS / 16
+            roof = {"bound": "mfma", "kernel": "gemm_kernel (bf16 v_mfma_f32_16x16x32; fwd+dgrad+wgrad launches)",
+                    "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                    "traffic": None, "launches_per_step": n.value // n_prof,
+                    "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
+                    "gemm_ms_per_step": round(ms.value / n_prof, 3)}
+    elif world > 1:
+        for _ in range(min(5, max(1, args.steps))):
+            step()
+        torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        imgs = B * world * args.steps
+        value = imgs / elapsed
+        line = {
+            "metric": "train images/sec (whole node), DiT-S/2 256^2 latent", "value": round(value, 1),
+            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{MODEL} (L12 D384 h6), 4x32x32 synthetic latents + pooled-text cond 1280, "
+                                   f"eps-MSE, AdamW lr1e-6 wd0.01 cosine; random-init weights",
+                       "per_gpu_batch": B, "global_batch": B * world, "tokens_per_image": 256,
+                       "parallelism": f"dp{world}"},
+            "model_tflops": round(value * STEP_GFLOP_PER_IMG / 1e3, 1),
+            "mfma_frac_whole_step": round(value * STEP_GFLOP_PER_IMG / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
+            "final_loss": round(final_loss, 5),
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline()
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

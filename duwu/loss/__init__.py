@@ -1,0 +1,2 @@
+"""reference src/duwu/loss/__init__.py."""
+from uwudiff_amd.objective import DiffusionLoss, DiffusionLossAuxOutput, RectifiedFlowLoss  # noqa: F401

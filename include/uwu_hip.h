@@ -119,6 +119,12 @@ int uwu_gemm(const void* A, const void* B, void* C, void* C2, const float* bias,
              int M, int N, int K, int lda, int ldb, int ldc, int ldaux, int transA, int transB, int dtype,
              int c_dtype, int epilogue, int split_k, void* stream);
 
+/* Live measurement for bench.py's `roofline` object: when enabled, every uwu_gemm launch is bracketed by a HIP
+ * event pair recorded on that launch's stream; collect() returns the summed launch duration, the summed
+ * algorithmic FLOPs (2*M*N*K) and the launch count for operand kind 0 (bf16) or 1 (fp32). */
+int uwu_gemm_prof_enable(int on);
+int uwu_gemm_prof_collect(int kind, double* ms, double* flops, int* launches);
+
 /* out[n] (+)= sum_m X[m,n]   (bias gradients). accumulate: 0 overwrite, 1 add. */
 int uwu_colsum(const void* X, int dtype, int M, int N, int ldx, float* out, int accumulate, void* stream);
 

@@ -273,6 +273,18 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmArgs g) {
   }
 }
 
+// ---- live profiler: HIP event pairs around GEMM launches on the launch stream (bench.py `roofline`) -------
+struct GemmProf {
+  static constexpr int MAXP = 8192;
+  bool on = false;
+  int n = 0;
+  hipEvent_t ev[2 * MAXP];
+  bool created = false;
+  double flops[MAXP];
+  int kind[MAXP];  // 0 = bf16 operands, 1 = fp32 operands
+};
+GemmProf g_prof;
+
 template <typename T, typename TC, bool TA, bool TB, bool ACC>
 int launch(const GemmArgs& g, int split, hipStream_t st) {
   auto kern = gemm_kernel<T, TC, TA, TB, ACC>;
@@ -283,7 +295,15 @@ int launch(const GemmArgs& g, int split, hipStream_t st) {
     attr_done = true;
   }
   dim3 grid(g.tiles_m * g.tiles_n, 1, split);
+  const bool rec = g_prof.on && g_prof.n < GemmProf::MAXP;
+  if (rec) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], st);
   hipLaunchKernelGGL(kern, grid, dim3(256), 4 * TILE_BYTES, st, g);
+  if (rec) {
+    (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st);
+    g_prof.flops[g_prof.n] = 2.0 * g.M * g.N * g.K;
+    g_prof.kind[g_prof.n] = sizeof(T) == 2 ? 0 : 1;
+    ++g_prof.n;
+  }
   UWU_LAUNCH_CHECK("gemm");
   return UWU_OK;
 }
@@ -356,4 +376,41 @@ extern "C" int uwu_gemm(const void* A, const void* B, void* C, void* C2, const f
     return dispatch_trans<bf16_t, float>(g, transA, transB, acc, split, st);
   }
   return dispatch_trans<float, float>(g, transA, transB, acc, split, st);
+}
+
+// Enable/disable recording of a HIP event pair around every uwu_gemm launch (on that launch's stream).
+extern "C" int uwu_gemm_prof_enable(int on) {
+  if (on && !g_prof.created) {
+    for (int i = 0; i < 2 * GemmProf::MAXP; ++i)
+      if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) {
+        uwu_set_error("gemm_prof: hipEventCreate failed");
+        return UWU_ELAUNCH;
+      }
+    g_prof.created = true;
+  }
+  g_prof.on = on != 0;
+  if (on) g_prof.n = 0;
+  return UWU_OK;
+}
+// Sum of launch durations (ms), algorithmic FLOPs (2*M*N*K) and launch count for operand kind (0 bf16, 1 fp32)
+// since the last enable; waits for the recorded events (host-side, outside any timed region).
+extern "C" int uwu_gemm_prof_collect(int kind, double* ms, double* flops, int* launches) {
+  double t = 0.0, f = 0.0;
+  int c = 0;
+  for (int i = 0; i < g_prof.n; ++i) {
+    if (g_prof.kind[i] != kind) continue;
+    float e = 0.f;
+    if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess ||
+        hipEventElapsedTime(&e, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) {
+      uwu_set_error("gemm_prof: event query failed");
+      return UWU_ELAUNCH;
+    }
+    t += e;
+    f += g_prof.flops[i];
+    ++c;
+  }
+  if (ms) *ms = t;
+  if (flops) *flops = f;
+  if (launches) *launches = c;
+  return UWU_OK;
 }

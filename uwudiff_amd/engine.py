@@ -1,0 +1,167 @@
+"""Step driver that replaces the subset of ``lightning.Trainer`` the reference's launcher uses
+(test_scripts/test_train.py:43-77): device placement, the fit loop, backward, data-parallel gradient exchange,
+global-norm clipping, optimizer + per-step LR schedule, rank-aware seeding, periodic logging.
+
+Lightning's loop is third-party control plane; the hot path it drives (loss -> denoiser fwd/bwd -> all-reduce ->
+clip -> AdamW) is the part this build implements natively.
+"""
+import json
+import os
+import random
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .gradsync import FlatGradSync
+from .optim import FusedAdamW
+
+
+def seed_everything(seed: int):
+    random.seed(seed)
+    np.random.seed(seed % (2 ** 32))
+    torch.manual_seed(seed)
+    return seed
+
+
+class ModelCheckpoint:
+    """Accepted for config compatibility (configs/demo_training.yaml:14-19); checkpointing is out of scope."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+
+class LearningRateMonitor:
+    def __init__(self, **kw):
+        self.kw = kw
+
+
+class GradualWarmupScheduler:
+    """``warmup_scheduler.GradualWarmupScheduler(optimizer, 1, warm_up_period, after)`` semantics
+    (reference trainer.py:61-64): lr = base_lr * step / period during warm-up, then ``after``."""
+
+    def __init__(self, optimizer, multiplier, total_epoch, after_scheduler=None):
+        assert multiplier == 1
+        self.optimizer, self.total, self.after = optimizer, total_epoch, after_scheduler
+        self.base = [g["lr"] for g in optimizer.param_groups]
+        self.n = 0
+        self._apply()
+
+    def _apply(self):
+        if self.n <= self.total:
+            for g, b in zip(self.optimizer.param_groups, self.base):
+                g["lr"] = b * (float(self.n) / self.total)
+
+    def step(self):
+        self.n += 1
+        if self.n > self.total and self.after is not None:
+            self.after.step()
+        else:
+            self._apply()
+
+
+def _dist_env():
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    return rank, world, local
+
+
+class Fitter:
+    def __init__(self, max_steps=-1, precision="bf16-mixed", gradient_clip_val=None, fast_dev_run=False,
+                 log_every_n_steps=10, accelerator="gpu", devices=1, strategy=None, callbacks=(), logger=(),
+                 max_epochs=None, **ignored):
+        self.max_steps = max_steps
+        self.precision = str(precision)
+        self.gradient_clip_val = gradient_clip_val
+        self.fast_dev_run = fast_dev_run
+        self.log_every_n_steps = max(1, int(log_every_n_steps))
+        self.max_epochs = max_epochs
+        self.global_rank, self.world_size, self.local_rank = _dist_env()
+        self.global_step = 0
+        self.history = []
+        if self.world_size > 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(self.local_rank)
+            self.device = torch.device("cuda", self.local_rank)
+        else:
+            self.device = torch.device("cpu")
+
+    @property
+    def compute_dtype(self):
+        return "fp32" if self.precision.startswith("32") else "bf16"
+
+    def _to_device(self, batch):
+        x, captions, tok, added, ca = batch
+        x = x.to(self.device, non_blocking=True)
+        tok = [{k: v.to(self.device, non_blocking=True) for k, v in t.items()} for t in tok]
+        added = {k: v.to(self.device, non_blocking=True) for k, v in added.items()}
+        return x, captions, tok, added, ca
+
+    def fit(self, module, datamodule, ckpt_path=None):
+        if hasattr(module.unet, "cfg"):
+            module.unet.cfg.compute_dtype = self.compute_dtype
+        module.to(self.device)
+        module._trainer = self
+        datamodule.setup("fit")
+        loader = datamodule.train_dataloader()
+        cfg = module.configure_optimizers()
+        opt = cfg["optimizer"] if isinstance(cfg, dict) else cfg
+        sched = cfg["lr_scheduler"]["scheduler"] if isinstance(cfg, dict) and "lr_scheduler" in cfg else None
+        sync = FlatGradSync(self.world_size)
+        params = [p for g in opt.param_groups for p in g["params"]]
+        max_steps = 1 if self.fast_dev_run else self.max_steps
+        t0 = time.time()
+        epoch = 0
+        done = False
+        while not done:
+            for batch in loader:
+                if 0 <= max_steps <= self.global_step:
+                    done = True
+                    break
+                module.global_step = self.global_step
+                for p in params:
+                    if p.grad is not None:
+                        p.grad.zero_()
+                out = module.training_step(self._to_device(batch), self.global_step)
+                loss = out["loss"]
+                loss.backward()
+                clip = None
+                if isinstance(opt, FusedAdamW):
+                    chunks = sync.all_reduce(params[0].grad)
+                    if self.gradient_clip_val:
+                        sync.wait_all()
+                        clip = opt.grad_norm_clip(self.gradient_clip_val, pre_scale=sync.pre_scale)
+                        opt.step(clip=clip, pre_scale=sync.pre_scale)
+                    else:
+                        opt.step(pre_scale=sync.pre_scale, chunks=chunks, before_chunk=sync.wait_chunk)
+                else:  # foreign optimizer (e.g. lion): plain torch path on the flat buffer
+                    for p in params:
+                        if self.world_size > 1:
+                            dist.all_reduce(p.grad)
+                            p.grad.mul_(1.0 / self.world_size)
+                    if self.gradient_clip_val:
+                        torch.nn.utils.clip_grad_norm_(params, self.gradient_clip_val)
+                    opt.step()
+                    if hasattr(module.unet, "refresh_shadow"):
+                        module.unet.refresh_shadow()
+                if sched is not None:
+                    sched.step()
+                self.global_step += 1
+                if self.global_step % self.log_every_n_steps == 0 or self.fast_dev_run or done:
+                    rec = {"step": self.global_step, "loss": float(loss.detach()), "ema_loss": float(module.ema_loss),
+                           "lr": opt.param_groups[0]["lr"], "elapsed_s": round(time.time() - t0, 3)}
+                    self.history.append(rec)
+                    if self.global_rank == 0:
+                        print(json.dumps(rec), flush=True)
+            epoch += 1
+            if self.max_epochs is not None and epoch >= self.max_epochs:
+                break
+            if max_steps < 0 and self.max_epochs is None:
+                break  # one pass when neither bound is given
+        if self.device.type == "cuda":
+            torch.cuda.synchronize()
+        return self.history

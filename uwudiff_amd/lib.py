@@ -49,6 +49,8 @@ _SIGS = {
     "uwu_cast_f32_to_bf16": (c_int, [P, P, c_int64, P]),
     "uwu_cast_bf16_to_f32": (c_int, [P, P, c_int64, P]),
     "uwu_gemm": (c_int, [P, P, P, P, P, P] + [c_int] * 13 + [P]),
+    "uwu_gemm_prof_enable": (c_int, [c_int]),
+    "uwu_gemm_prof_collect": (c_int, [c_int, P, P, P]),
     "uwu_colsum": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, P]),
     "uwu_add_ln_modulate_fwd": (c_int, [P, P, P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_float, c_int, P]),
     "uwu_add_ln_modulate_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),

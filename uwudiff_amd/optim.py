@@ -39,7 +39,9 @@ class FusedAdamW(torch.optim.Optimizer):
         return out
 
     @torch.no_grad()
-    def step(self, closure=None, clip=None, pre_scale=1.0):
+    def step(self, closure=None, clip=None, pre_scale=1.0, chunks=None, before_chunk=None):
+        """One AdamW update.  ``chunks`` = [(offset, length), ...] splits the launch over sub-ranges of the flat
+        buffer (16-byte aligned offsets); ``before_chunk(i)`` is called first (waits for chunk i's all-reduce)."""
         loss = closure() if closure is not None else None
         for group in self.param_groups:
             b1, b2 = group["betas"]
@@ -53,10 +55,17 @@ class FusedAdamW(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p.data)
                 st["step"] += 1
                 shadow = getattr(p, "_uwu_bf16_shadow", None)
-                L.call("uwu_adamw_step", L.ptr(p.data), L.ptr(p.grad), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]),
-                       L.ptr(shadow) if shadow is not None and shadow.numel() == p.numel() else None, p.numel(),
-                       float(group["lr"]), b1, b2, group["eps"], group["weight_decay"], st["step"], float(pre_scale),
-                       L.ptr(clip) if clip is not None else None, L.stream())
+                if shadow is not None and shadow.numel() != p.numel():
+                    shadow = None
+                flat = [p.data.view(-1), p.grad.view(-1), st["exp_avg"].view(-1), st["exp_avg_sq"].view(-1)]
+                for i, (off, ln) in enumerate(chunks or [(0, p.numel())]):
+                    if before_chunk is not None:
+                        before_chunk(i)
+                    ptrs = [t.data_ptr() + 4 * off for t in flat]
+                    sp = shadow.data_ptr() + 2 * off if shadow is not None else None
+                    L.call("uwu_adamw_step", ptrs[0], ptrs[1], ptrs[2], ptrs[3], sp, ln, float(group["lr"]), b1, b2,
+                           group["eps"], group["weight_decay"], st["step"], float(pre_scale),
+                           L.ptr(clip) if clip is not None else None, L.stream())
         return loss
 
 
