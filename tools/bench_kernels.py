@@ -59,7 +59,8 @@ def main():
             if ta:
                 out = torch.zeros(m, n, device=dev)
                 tiles = ((m + 127) // 128) * ((n + 127) // 128)
-                split = max(1, min((512 + tiles - 1) // tiles, (k + 63) // 64))
+                target = int(os.environ.get('UWU_WGRAD_BLOCKS', '512'))
+                split = max(1, min((target + tiles - 1) // tiles, (k + 63) // 64))
                 fn = lambda: ops.gemm(a, b, trans_a=True, trans_b=True, epilogue=L.EPI_ACCUM, out=out, split_k=split)
             else:
                 out = torch.empty(m, n, device=dev, dtype=bf)

@@ -154,7 +154,10 @@ int lin_wgrad(const void* dY, const void* X, float* dW, int M, int N, int K, int
   const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
   const int bk = dt == UWU_BF16 ? 64 : 32;
   const int ktiles = (M + bk - 1) / bk;
-  int split = (512 + tiles - 1) / tiles;
+  // measured sweep (tools/bench_kernels.py, UWU_WGRAD_BLOCKS): ~3 workgroups per CU for the large weight
+  // matrices, ~1 per CU when only a few output tiles exist (the atomic traffic tiles*split*64 KB dominates there)
+  const int target = tiles >= 16 ? 768 : 256;
+  int split = (target + tiles - 1) / tiles;
   if (split > ktiles) split = ktiles;
   if (split < 1) split = 1;
   return uwu_gemm(dY, X, dW, nullptr, nullptr, nullptr, N, K, M, N, K, K, 0, 1, 1, dt, UWU_F32, UWU_EPI_ACCUM, split, st);

@@ -18,6 +18,8 @@
 // the e-th 16x16x4 MFMA, i.e. a k-permutation applied identically to A and B.
 // Global->LDS goes through registers (prefetch of tile t+1 issued before the MFMAs of tile t); K-strided
 // operands are transposed in registers (4x8 bf16 / 4x4 fp32 blocks) so HBM reads stay 16 B/lane coalesced.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -115,6 +117,29 @@ struct Stager {
   }
 };
 
+// LDS-DMA staging of a K-contiguous 128-row tile (global_load_lds_dwordx4: no VGPR round trip, no ds_write).
+// One wave-instruction fills 8 rows x 128 B; the LDS image must be lane-linear, so the chunk swizzle is applied
+// to the per-lane SOURCE address (lane l lands at chunk position l&7 of row l>>3, hence fetches logical chunk
+// (l&7) ^ f(row)); rows past the operand's extent are clamped (their products are never stored).
+// Requires full K tiles (K % BK == 0).
+template <typename T>
+__device__ __forceinline__ void glds_tile(const T* __restrict__ base, int ld, int row0, int k0, int nrows,
+                                          char* __restrict__ lds_tile, int tid) {
+  constexpr int EPC = GT<T>::EPC;
+  const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int grp = wave + 4 * g;
+    const int row = 8 * grp + (lane >> 3);
+    const int c = ((lane & 7) ^ (row >> 1) ^ (row >> 4)) & 7;
+    int grow = row0 + row;
+    if (grow >= nrows) grow = nrows - 1;
+    const T* src = base + (int64_t)grow * ld + k0 + c * EPC;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(lds_tile + grp * 1024), 16, 0, 0);
+  }
+}
+
 template <typename T>
 __device__ __forceinline__ void mma_frag(const uint4& a, const uint4& b, f32x4& c) {
   if constexpr (sizeof(T) == 2) {
@@ -135,13 +160,14 @@ struct GemmArgs {
   void* C2;
   const float* bias;
   const void* aux;
-  int M, N, K, lda, ldb, ldc, ldaux, epi, tiles_m, tiles_n, k_tiles_per_split;
+  int M, N, K, lda, ldb, ldc, ldaux, epi, tiles_m, tiles_n, k_tiles_per_split, wide;
 };
 
 // ACC = atomic-accumulate epilogue (standard accumulator orientation: registers walk rows, lanes walk
 // 16 consecutive columns -> 64-B atomic segments).  Otherwise the MFMA operands are swapped so that each lane
 // owns 4 consecutive columns of one row and can apply the epilogue on / store 8-16 B vectors directly.
-template <typename T, typename TC, bool TA, bool TB, bool ACC>
+// GL = LDS-DMA staging (only with TA = TB = false and full K tiles).
+template <typename T, typename TC, bool TA, bool TB, bool ACC, bool GL = false>
 __global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BK = GT<T>::BK;
@@ -177,10 +203,15 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  sa.load(A, g.lda, m0, kt_begin * BK, g.M, g.K, tid);
-  sb.load(B, g.ldb, n0, kt_begin * BK, g.N, g.K, tid);
-  sa.store(smem, tid);
-  sb.store(smem + TILE_BYTES, tid);
+  if constexpr (GL) {
+    glds_tile<T>(A, g.lda, m0, kt_begin * BK, g.M, smem, tid);
+    glds_tile<T>(B, g.ldb, n0, kt_begin * BK, g.N, smem + TILE_BYTES, tid);
+  } else {
+    sa.load(A, g.lda, m0, kt_begin * BK, g.M, g.K, tid);
+    sb.load(B, g.ldb, n0, kt_begin * BK, g.N, g.K, tid);
+    sa.store(smem, tid);
+    sb.store(smem + TILE_BYTES, tid);
+  }
   __syncthreads();
 
   const int fr = lane & 15, fq = lane >> 4;
@@ -189,9 +220,15 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmArgs g) {
     const char* la = smem + cur * 2 * TILE_BYTES;
     const char* lb = la + TILE_BYTES;
     const bool more = (kt + 1 < kt_end);
-    if (more) {  // prefetch next tile into registers; latency hides under the MFMAs below
-      sa.load(A, g.lda, m0, (kt + 1) * BK, g.M, g.K, tid);
-      sb.load(B, g.ldb, n0, (kt + 1) * BK, g.N, g.K, tid);
+    if (more) {
+      if constexpr (GL) {  // DMA the next tile straight into the other stage (free since the last barrier)
+        char* na = smem + (cur ^ 1) * 2 * TILE_BYTES;
+        glds_tile<T>(A, g.lda, m0, (kt + 1) * BK, g.M, na, tid);
+        glds_tile<T>(B, g.ldb, n0, (kt + 1) * BK, g.N, na + TILE_BYTES, tid);
+      } else {  // prefetch next tile into registers; latency hides under the MFMAs below
+        sa.load(A, g.lda, m0, (kt + 1) * BK, g.M, g.K, tid);
+        sb.load(B, g.ldb, n0, (kt + 1) * BK, g.N, g.K, tid);
+      }
     }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -212,12 +249,14 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmArgs g) {
             mma_frag<T>(bf[j], af[i], acc[i][j]);
         }
     }
-    if (more) {
-      char* na = smem + (cur ^ 1) * 2 * TILE_BYTES;
-      sa.store(na, tid);
-      sb.store(na + TILE_BYTES, tid);
+    if constexpr (!GL) {
+      if (more) {
+        char* na = smem + (cur ^ 1) * 2 * TILE_BYTES;
+        sa.store(na, tid);
+        sb.store(na + TILE_BYTES, tid);
+      }
     }
-    __syncthreads();
+    __syncthreads();  // with LDS-DMA outstanding hipcc drains vmcnt(0) here: the next stage is complete
   }
 
   // ---------------------------------------------------------------- epilogue
@@ -239,6 +278,66 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmArgs g) {
     TC* C2 = static_cast<TC*>(g.C2);
     const T* aux = static_cast<const T*>(g.aux);
     const int epi = g.epi;
+    // per-subtile epilogue math on this lane's 4 consecutive columns
+    auto finish = [&](f32x4 v, int m, int n, f32x4& second) {
+      if (epi == UWU_EPI_BIAS || epi == UWU_EPI_BIAS_GELU || epi == UWU_EPI_BIAS_SILU) v = v + load4(g.bias + n);
+      if (epi == UWU_EPI_DGELU) {
+        f32x4 u = load4(aux + (int64_t)m * g.ldaux + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= dgelu_tanh_f(u[e]);
+      }
+      if (epi == UWU_EPI_BIAS_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) second[e] = gelu_tanh_f(v[e]);
+      } else if (epi == UWU_EPI_BIAS_SILU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) second[e] = silu_f(v[e]);
+      }
+      return v;
+    };
+    const bool two = epi == UWU_EPI_BIAS_GELU || epi == UWU_EPI_BIAS_SILU;
+    if constexpr (sizeof(TC) == 2) {
+      // bf16 output: stores are instruction-bound (fp32 output of the same tile costs the same per store), so
+      // pair lanes l and l^16 (column groups fq, fq^1) and swap half of two neighbouring 16-column subtiles:
+      // even fq keeps subtile 2jp (own 4 columns + partner's next 4), odd fq keeps subtile 2jp+1 -> one 16-B store
+      // per lane covering 8 consecutive columns, 64 contiguous bytes per row per instruction, half the stores.
+      if (g.wide) {
+        const bool odd = fq & 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = m0 + wm * 64 + 16 * i + fr;
+          const bool mok = m < g.M;
+#pragma unroll
+          for (int jp = 0; jp < 2; ++jp) {
+            const int nb = n0 + wn * 64 + 32 * jp;  // first column of subtile 2jp
+            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+            const int na = nb + 4 * fq, nc = nb + 16 + 4 * fq;
+            const bool oka = mok && na < g.N, okc = mok && nc < g.N;
+            f32x4 v0 = oka ? finish(acc[i][2 * jp], m, na, s0) : acc[i][2 * jp];
+            f32x4 v1 = okc ? finish(acc[i][2 * jp + 1], m, nc, s1) : acc[i][2 * jp + 1];
+            auto pack = [](const f32x4& v) {
+              bf16x4 b = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+              return *reinterpret_cast<uint2*>(&b);
+            };
+            auto exchange_store = [&](TC* dst, const f32x4& x0, const f32x4& x1) {
+              const uint2 p0 = pack(x0), p1 = pack(x1);
+              const uint2 send = odd ? p0 : p1;
+              uint2 recv;
+              recv.x = __shfl_xor(send.x, 16, 64);
+              recv.y = __shfl_xor(send.y, 16, 64);
+              const int n = odd ? nb + 16 + 4 * (fq - 1) : nb + 4 * fq;
+              if (mok && n < g.N) {
+                const uint4 o = odd ? uint4{recv.x, recv.y, p1.x, p1.y} : uint4{p0.x, p0.y, recv.x, recv.y};
+                *reinterpret_cast<uint4*>(dst + (int64_t)m * g.ldc + n) = o;
+              }
+            };
+            exchange_store(C, v0, v1);
+            if (two) exchange_store(C2, s0, s1);
+          }
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = m0 + wm * 64 + 16 * i + fr;
@@ -246,28 +345,10 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmArgs g) {
       for (int j = 0; j < 4; ++j) {
         const int n = n0 + wn * 64 + 16 * j + 4 * fq;
         if (m >= g.M || n >= g.N) continue;
-        f32x4 v = acc[i][j];
-        if (epi == UWU_EPI_BIAS || epi == UWU_EPI_BIAS_GELU || epi == UWU_EPI_BIAS_SILU) {
-          f32x4 bv = load4(g.bias + n);
-          v = v + bv;
-        }
-        if (epi == UWU_EPI_DGELU) {
-          f32x4 u = load4(aux + (int64_t)m * g.ldaux + n);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] *= dgelu_tanh_f(u[e]);
-        }
+        f32x4 second = {0.f, 0.f, 0.f, 0.f};
+        f32x4 v = finish(acc[i][j], m, n, second);
         store4(C + (int64_t)m * g.ldc + n, v);
-        if (epi == UWU_EPI_BIAS_GELU) {
-          f32x4 a2;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) a2[e] = gelu_tanh_f(v[e]);
-          store4(C2 + (int64_t)m * g.ldc + n, a2);
-        } else if (epi == UWU_EPI_BIAS_SILU) {
-          f32x4 a2;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) a2[e] = silu_f(v[e]);
-          store4(C2 + (int64_t)m * g.ldc + n, a2);
-        }
+        if (two) store4(C2 + (int64_t)m * g.ldc + n, second);
       }
     }
   }
@@ -285,9 +366,9 @@ struct GemmProf {
 };
 GemmProf g_prof;
 
-template <typename T, typename TC, bool TA, bool TB, bool ACC>
+template <typename T, typename TC, bool TA, bool TB, bool ACC, bool GL = false>
 int launch(const GemmArgs& g, int split, hipStream_t st) {
-  auto kern = gemm_kernel<T, TC, TA, TB, ACC>;
+  auto kern = gemm_kernel<T, TC, TA, TB, ACC, GL>;
   static bool attr_done = false;  // per instantiation
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -308,6 +389,15 @@ int launch(const GemmArgs& g, int split, hipStream_t st) {
   return UWU_OK;
 }
 
+bool no_glds() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("UWU_GEMM_NO_GLDS");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v == 1;
+}
+
 template <typename T, typename TC>
 int dispatch_trans(const GemmArgs& g, int ta, int tb, bool acc, int split, hipStream_t st) {
   if (acc) {
@@ -319,7 +409,10 @@ int dispatch_trans(const GemmArgs& g, int ta, int tb, bool acc, int split, hipSt
     uwu_set_error("gemm: ACCUM epilogue needs fp32 C and (transA,transB) in {(0,0),(0,1),(1,1)}");
     return UWU_EINVAL;
   }
-  if (ta == 0 && tb == 0) return launch<T, TC, false, false, false>(g, split, st);
+  if (ta == 0 && tb == 0) {
+    if (g.K % GT<T>::BK == 0 && !no_glds()) return launch<T, TC, false, false, false, true>(g, split, st);
+    return launch<T, TC, false, false, false>(g, split, st);
+  }
   if (ta == 0 && tb == 1) return launch<T, TC, false, true, false>(g, split, st);
   if (ta == 1 && tb == 1) return launch<T, TC, true, true, false>(g, split, st);
   uwu_set_error("gemm: (transA=1, transB=0) is not instantiated");
@@ -327,6 +420,11 @@ int dispatch_trans(const GemmArgs& g, int ta, int tb, bool acc, int split, hipSt
 }
 
 }  // namespace
+
+// 4-stage LDS-DMA ring kernel for the K-contiguous case (gemm_ring.hip)
+bool uwu_gemm_ring_ok(int K, int dtype);
+int uwu_gemm_ring(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux, int M, int N,
+                  int K, int lda, int ldb, int ldc, int ldaux, int dtype, int c_dtype, int epilogue, hipStream_t st);
 
 extern "C" int uwu_gemm(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux, int M,
                         int N, int K, int lda, int ldb, int ldc, int ldaux, int transA, int transB, int dtype,
@@ -360,11 +458,28 @@ extern "C" int uwu_gemm(const void* A, const void* B, void* C, void* C2, const f
   } else {
     UWU_CHECK_ARG(c_dtype == UWU_F32 && ldc >= N, "gemm: ACCUM needs fp32 C");
   }
+  if (!transA && !transB && !acc && uwu_gemm_ring_ok(K, dtype)) {
+    const bool rec = g_prof.on && g_prof.n < GemmProf::MAXP;
+    if (rec) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], (hipStream_t)stream);
+    int rc = uwu_gemm_ring(A, B, C, C2, bias, aux, M, N, K, lda, ldb, ldc, ldaux, dtype, c_dtype, epilogue,
+                           (hipStream_t)stream);
+    if (rec) {
+      (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], (hipStream_t)stream);
+      g_prof.flops[g_prof.n] = 2.0 * M * N * K;
+      g_prof.kind[g_prof.n] = dtype == UWU_BF16 ? 0 : 1;
+      ++g_prof.n;
+    }
+    return rc;
+  }
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.C2 = C2; g.bias = bias; g.aux = aux;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux; g.epi = epilogue;
   g.tiles_m = (M + BM - 1) / BM;
   g.tiles_n = (N + BN - 1) / BN;
+  // 16-byte epilogue stores need 8-column granularity and 16-byte aligned rows
+  g.wide = (!acc && c_dtype == UWU_BF16 && N % 8 == 0 && ldc % 8 == 0 && ((uintptr_t)C & 15) == 0 &&
+            (C2 == nullptr || ((uintptr_t)C2 & 15) == 0)) ? 1 : 0;
+
   const int ktiles = (K + bk - 1) / bk;
   int split = split_k < 1 ? 1 : split_k;
   if (split > ktiles) split = ktiles;
