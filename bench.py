@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--clip", type=float, default=0.0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL over xGMI) for real runs; gloo lets several ranks share ONE GPU to rehearse the "
+                         "multi-process path on a 1-GPU box")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -94,11 +97,16 @@ def main():
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
         if world == 1 and args.gpus > 1:
             sys.exit(2)
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1) if args.backend == "gloo" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     from uwudiff_amd import lib as L
     from uwudiff_amd.dit import DiT
