@@ -127,16 +127,21 @@ int uwu_gemm_prof_collect(int kind, double* ms, double* flops, int* launches);
 
 /* out[n] (+)= sum_m X[m,n]   (bias gradients). accumulate: 0 overwrite, 1 add. */
 int uwu_colsum(const void* X, int dtype, int M, int N, int ldx, float* out, int accumulate, void* stream);
+/* batched: out[b, n] (+)= sum_m X[b, m, n] for `batch` contiguous [M, ldx] slabs. */
+int uwu_colsum_batched(const void* X, int dtype, int batch, int M, int N, int ldx, float* out, int accumulate,
+                       void* stream);
 
 /* ------------------------------------------------------------------ norms / modulation (a13) */
 
 /* adaLN-Zero pre-norm with fused residual update (rope_unet.py:306-309, 344-349, 393-411):
  *   x_out = x_in + gate_b * y            (y/gate may be NULL: x_out = x_in, not written if x_out==x_in)
- *   h     = LayerNorm(x_out; eps, no affine) * (1 + scale_b) + shift_b
+ *   h     = LayerNorm(x_out; eps, no affine) * (1 + scale_b) + shift_b          (affine = 0, adaLN-Zero)
+ *   h     = LayerNorm(x_out; eps) * scale + shift   with mod_ld = 0: one shared (gamma, beta) row  (affine = 1,
+ *           the plain pre-LN of the SDXL transformer blocks; dscale/dshift then are dgamma/dbeta)
  * x_*, y, h: [B*T, D] in `dtype`; shift/scale/gate: fp32 rows of a [B, mod_ld] buffer; mean/rstd fp32[B*T]. */
 int uwu_add_ln_modulate_fwd(const void* x_in, const void* y, const float* gate, const float* shift,
                             const float* scale, int mod_ld, void* x_out, void* h, float* mean, float* rstd,
-                            int B, int T, int D, float eps, int dtype, void* stream);
+                            int B, int T, int D, float eps, int affine, int dtype, void* stream);
 
 /* Backward of the above, fused with the residual/gate backward of the branch that feeds x:
  *   dx_out = dx_in + LN_bwd(dh * (1+scale_b))        (dx_in may be NULL for the last norm)
@@ -146,7 +151,7 @@ int uwu_add_ln_modulate_fwd(const void* x_in, const void* y, const float* gate, 
 int uwu_add_ln_modulate_bwd(const void* dh, const void* x, const float* mean, const float* rstd,
                             const float* scale, const void* dx_in, const void* y, const float* gate,
                             int mod_ld, void* dx_out, void* dy, float* dshift, float* dscale, float* dgate,
-                            int B, int T, int D, int dtype, void* stream);
+                            int B, int T, int D, int affine, int dtype, void* stream);
 
 /* ------------------------------------------------------------------ attention (a12) */
 
@@ -180,6 +185,32 @@ int uwu_patchify(const float* img, void* tok, int B, int C, int H, int W, int p,
 int uwu_unpatchify(const void* tok, int dtype, float* img, int B, int C, int H, int W, int p, void* stream);
 /* x[b,t,:] += pos[t,:]  (fixed 2-D sin-cos table, fp32 [T,D]) */
 int uwu_add_pos(void* x, const float* pos, int B, int T, int D, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ UNet2DConditionModel-shape denoiser (a11) */
+/* Channels-last activations x[b, p, c] (p = y*W + x).  Replace the torch/diffusers op sequences of
+ * ResnetBlock2D / Transformer2DModel / Down-/Upsample2D (reference src/duwu/modules/unet_patch.py:13-57). */
+
+/* y = GroupNorm(x; G groups, eps, gamma, beta) [then SiLU if silu]; mean/rstd: fp32 [B*G]. */
+int uwu_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                      int B, int HW, int C, int G, float eps, int silu, int dtype, void* stream);
+/* dgamma/dbeta are accumulated (fp32 atomics). */
+int uwu_groupnorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                      const float* beta, void* dx, float* dgamma, float* dbeta, int B, int HW, int C, int G,
+                      int silu, int dtype, void* stream);
+/* 3x3 / padding 1 / stride 1|2 convolution = im2col + uwu_gemm: col[(b,oy,ox), (ky,kx,c)]; col2im is the adjoint
+ * in gather form (no atomics). */
+int uwu_im2col3x3(const void* x, void* col, int B, int H, int W, int C, int stride, int dtype, void* stream);
+int uwu_col2im3x3(const void* dcol, void* dx, int B, int H, int W, int C, int stride, int dtype, void* stream);
+/* GEGLU feed-forward gate: hg [M, 2F] = (h | gate) -> out [M, F] = h * gelu_erf(gate), and its backward. */
+int uwu_geglu_fwd(const void* hg, void* out, int64_t M, int F, int dtype, void* stream);
+int uwu_geglu_bwd(const void* hg, const void* dout, void* dhg, int64_t M, int F, int dtype, void* stream);
+/* nearest-neighbour 2x upsample [B,H,W,C] -> [B,2H,2W,C]; backward=1: src is d(out) [B,2H,2W,C], dst d(in). */
+int uwu_upsample2x(const void* src, void* dst, int B, int H, int W, int C, int backward, int dtype, void* stream);
+/* x[b, p, :] += v[b, :] (time-embedding injection). */
+int uwu_add_rowvec(void* x, const void* v, int B, int HW, int C, int dtype, void* stream);
+/* NCHW fp32 <-> channels-last (dtype). */
+int uwu_nchw_to_cl(const float* nchw, void* cl, int B, int C, int HW, int dtype, void* stream);
+int uwu_cl_to_nchw(const void* cl, float* nchw, int B, int C, int HW, int dtype, void* stream);
 
 /* ------------------------------------------------------------------ whole-network drivers */
 

@@ -265,12 +265,12 @@ extern "C" int uwu_dit_forward(const uwu_dit_desc* dp, const float* noisy, const
     // LN1 (+ pending MLP branch of the previous layer: x0 = x1_prev + gate_mlp_prev * y2_prev)
     if (l == 0) {
       RUN(uwu_add_ln_modulate_fwd(x0, nullptr, nullptr, m + 0, m + D, ML, x0, P.lay(l, L.o_h1),
-                                  P.lay<float>(l, L.o_m1), P.lay<float>(l, L.o_r1), B, T, D, d.ln_eps, dt, st));
+                                  P.lay<float>(l, L.o_m1), P.lay<float>(l, L.o_r1), B, T, D, d.ln_eps, 0, dt, st));
     } else {
       const float* mp = mod + (int64_t)(l - 1) * 6 * D;
       RUN(uwu_add_ln_modulate_fwd(P.lay(l - 1, L.o_x1), P.lay(l - 1, L.o_y2), mp + 5 * D, m + 0, m + D, ML, x0,
                                   P.lay(l, L.o_h1), P.lay<float>(l, L.o_m1), P.lay<float>(l, L.o_r1), B, T, D,
-                                  d.ln_eps, dt, st));
+                                  d.ln_eps, 0, dt, st));
     }
     RUN(lin_fwd(P.lay(l, L.o_h1), w.qkv_w, w.qkv_b, P.lay(l, L.o_qkv), nullptr, M, D3, D, dt, dt, UWU_EPI_BIAS, st));
     char* qkv = P.lay<char>(l, L.o_qkv);
@@ -280,7 +280,7 @@ extern "C" int uwu_dit_forward(const uwu_dit_desc* dp, const float* noisy, const
     // x1 = x0 + gate_msa * y1 ; h2 = LN(x1)*(1+scale_mlp)+shift_mlp
     RUN(uwu_add_ln_modulate_fwd(x0, P.lay(l, L.o_y1), m + 2 * D, m + 3 * D, m + 4 * D, ML, P.lay(l, L.o_x1),
                                 P.lay(l, L.o_h2), P.lay<float>(l, L.o_m2), P.lay<float>(l, L.o_r2), B, T, D, d.ln_eps,
-                                dt, st));
+                                0, dt, st));
     RUN(lin_fwd(P.lay(l, L.o_h2), w.fc1_w, w.fc1_b, P.lay(l, L.o_u), P.lay(l, L.o_f), M, D4, D, dt, dt,
                 UWU_EPI_BIAS_GELU, st));
     RUN(lin_fwd(P.lay(l, L.o_f), w.fc2_w, w.fc2_b, P.lay(l, L.o_y2), nullptr, M, D, D4, dt, dt, UWU_EPI_BIAS, st));
@@ -291,7 +291,7 @@ extern "C" int uwu_dit_forward(const uwu_dit_desc* dp, const float* noisy, const
     const float* mp = mod + (int64_t)l * 6 * D;
     const float* mf = mod + (int64_t)d.L * 6 * D;  // shift, scale
     RUN(uwu_add_ln_modulate_fwd(P.lay(l, L.o_x1), P.lay(l, L.o_y2), mp + 5 * D, mf + 0, mf + D, ML, P.at(L.xF),
-                                P.at(L.hF), P.at<float>(L.mF), P.at<float>(L.rF), B, T, D, d.ln_eps, dt, st));
+                                P.at(L.hF), P.at<float>(L.mF), P.at<float>(L.rF), B, T, D, d.ln_eps, 0, dt, st));
     RUN(lin_fwd(P.at(L.hF), wb + d.off_final_w * es, w32 + d.off_final_b, P.at(L.otok), nullptr, M, (int)L.Ko, D, dt, dt,
                 UWU_EPI_BIAS, st));
     RUN(uwu_unpatchify(P.at(L.otok), dt, out, B, d.out_ch, d.img, d.img, d.patch, st));
@@ -334,7 +334,7 @@ extern "C" int uwu_dit_backward(const uwu_dit_desc* dp, const float* dout, void*
     // final LN bwd + gate bwd of the last MLP branch: dx = d/d x1_{L-1}; dy = gate_mlp * dx
     RUN(uwu_add_ln_modulate_bwd(P.at(L.dh), P.at(L.xF), P.at<float>(L.mF), P.at<float>(L.rF), mf + D, nullptr,
                                 P.lay(l, L.o_y2), mp + 5 * D, ML, P.at(L.dx), P.at(L.dy), dmf + 0, dmf + D, dmp + 5 * D,
-                                B, T, D, dt, st));
+                                B, T, D, 0, dt, st));
   }
   for (int l = d.L - 1; l >= 0; --l) {
     const LayerW w = layer_weights(d, l);
@@ -350,7 +350,7 @@ extern "C" int uwu_dit_backward(const uwu_dit_desc* dp, const float* dout, void*
     // LN2 bwd (+ residual) and gate bwd of the attention branch
     RUN(uwu_add_ln_modulate_bwd(P.at(L.dh), P.lay(l, L.o_x1), P.lay<float>(l, L.o_m2), P.lay<float>(l, L.o_r2), m + 4 * D,
                                 P.at(L.dx), P.lay(l, L.o_y1), m + 2 * D, ML, P.at(L.dx), P.at(L.dy), dm + 3 * D,
-                                dm + 4 * D, dm + 2 * D, B, T, D, dt, st));
+                                dm + 4 * D, dm + 2 * D, B, T, D, 0, dt, st));
     // ---- attention branch: y1 = proj(attn(qkv(h1)))
     RUN(lin_wgrad(P.at(L.dy), P.lay(l, L.o_ao), g + w.off_o_w, M, D, D, dt, st));
     RUN(uwu_colsum(P.at(L.dy), dt, M, D, D, g + w.off_o_b, 1, st));
@@ -369,11 +369,10 @@ extern "C" int uwu_dit_backward(const uwu_dit_desc* dp, const float* dout, void*
       float* dmp = dmod + (int64_t)(l - 1) * 6 * D;
       RUN(uwu_add_ln_modulate_bwd(P.at(L.dh), P.lay(l, L.o_x0), P.lay<float>(l, L.o_m1), P.lay<float>(l, L.o_r1), m + D,
                                   P.at(L.dx), P.lay(l - 1, L.o_y2), mp + 5 * D, ML, P.at(L.dx), P.at(L.dy), dm + 0,
-                                  dm + D, dmp + 5 * D, B, T, D, dt, st));
+                                  dm + D, dmp + 5 * D, B, T, D, 0, dt, st));
     } else {
       RUN(uwu_add_ln_modulate_bwd(P.at(L.dh), P.lay(l, L.o_x0), P.lay<float>(l, L.o_m1), P.lay<float>(l, L.o_r1), m + D,
-                                  P.at(L.dx), nullptr, nullptr, ML, P.at(L.dx), nullptr, dm + 0, dm + D, nullptr, B, T,
-                                  D, dt, st));
+                                  P.at(L.dx), nullptr, nullptr, ML, P.at(L.dx), nullptr, dm + 0, dm + D, nullptr, B, T, D, 0, dt, st));
     }
   }
   // ---- patch embedding (input latents need no gradient; positions are fixed)

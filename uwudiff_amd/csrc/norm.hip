@@ -15,7 +15,7 @@ __global__ void __launch_bounds__(256) add_ln_mod_fwd_kernel(const T* __restrict
                                                              const float* __restrict__ scale, int mod_ld,
                                                              T* __restrict__ x_out, T* __restrict__ h,
                                                              float* __restrict__ mean_o, float* __restrict__ rstd_o,
-                                                             int M, int T_tok, int D, float eps) {
+                                                             int M, int T_tok, int D, float eps, int affine) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nit = (D + 255) >> 8;
   for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256) add_ln_mod_fwd_kernel(const T* __restrict
         if (scale) {
           f32x4 sc = load4(scale + (int64_t)b * mod_ld + d), sh = load4(shift + (int64_t)b * mod_ld + d);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = o[e] * (1.f + sc[e]) + sh[e];
+          for (int e = 0; e < 4; ++e) o[e] = o[e] * (affine ? sc[e] : 1.f + sc[e]) + sh[e];
         }
         store4(h + off + d, o);
       }
@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(256) add_ln_mod_bwd_kernel(
     const float* __restrict__ rstd_i, const float* __restrict__ scale, const T* __restrict__ dx_in,
     const T* __restrict__ y, const float* __restrict__ gate, int mod_ld, T* __restrict__ dx_out, T* __restrict__ dy,
     float* __restrict__ dshift, float* __restrict__ dscale, float* __restrict__ dgate, int M, int T_tok, int D,
-    int rows_per_block) {
+    int rows_per_block, int affine) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][3][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nit = (D + 255) >> 8;
@@ -112,11 +112,12 @@ __global__ void __launch_bounds__(256) add_ln_mod_bwd_kernel(
       const int d = it * 256 + lane * 4;
       if (it < nit && d < D) {
         f32x4 xv = load4(x + off + d), dv = load4(dh + off + d);
-        f32x4 sc = scale ? load4(scale + (int64_t)b * mod_ld + d) : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 sc = scale ? load4(scale + (int64_t)b * mod_ld + d)
+                         : (affine ? f32x4{1.f, 1.f, 1.f, 1.f} : f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float xhat = (xv[e] - mean) * rstd;
-          float gg = dv[e] * (1.f + sc[e]);
+          float gg = dv[e] * (affine ? sc[e] : 1.f + sc[e]);
           xh[it][e] = xhat;
           g[it][e] = gg;
           s1 += gg;
@@ -174,6 +175,8 @@ __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ X, in
   __shared__ f32x4 red[16][17];
   const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
   const int n = blockIdx.x * 64 + cg * 4;
+  X += (int64_t)blockIdx.z * M * ldx;  // batched form: gridDim.z independent [M, N] slabs -> out[z, :]
+  out += (int64_t)blockIdx.z * N;
   const int r0 = blockIdx.y * rows_per_block;
   int r1 = r0 + rows_per_block;
   if (r1 > M) r1 = M;
@@ -195,7 +198,7 @@ __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ X, in
 
 extern "C" int uwu_add_ln_modulate_fwd(const void* x_in, const void* y, const float* gate, const float* shift,
                                        const float* scale, int mod_ld, void* x_out, void* h, float* mean, float* rstd,
-                                       int B, int T, int D, float eps, int dtype, void* stream) {
+                                       int B, int T, int D, float eps, int affine, int dtype, void* stream) {
   UWU_CHECK_ARG(x_in && h && mean && rstd, "add_ln_modulate_fwd: null pointer");
   UWU_CHECK_ARG(B > 0 && T > 0 && D > 0 && D % 4 == 0 && D <= MAX_D, "add_ln_modulate_fwd: D=%d unsupported", D);
   UWU_CHECK_ARG((y == nullptr) || (gate && x_out), "add_ln_modulate_fwd: y needs gate and x_out");
@@ -211,11 +214,11 @@ extern "C" int uwu_add_ln_modulate_fwd(const void* x_in, const void* y, const fl
     if (dtype == UWU_F32)                                                                                          \
       hipLaunchKernelGGL((add_ln_mod_fwd_kernel<float, NIT>), dim3(grid), dim3(256), 0, st, (const float*)x_in,    \
                          (const float*)y, gate, shift, scale, mod_ld, (float*)x_out, (float*)h, mean, rstd, M, T, D, \
-                         eps);                                                                                     \
+                         eps, affine);                                                                                     \
     else                                                                                                           \
       hipLaunchKernelGGL((add_ln_mod_fwd_kernel<bf16_t, NIT>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x_in,  \
                          (const bf16_t*)y, gate, shift, scale, mod_ld, (bf16_t*)x_out, (bf16_t*)h, mean, rstd, M,  \
-                         T, D, eps);                                                                               \
+                         T, D, eps, affine);                                                                               \
     break;
   switch ((D + 255) / 256) {
     FWD_CASE(1) FWD_CASE(2) FWD_CASE(3) FWD_CASE(4) FWD_CASE(5) FWD_CASE(6) FWD_CASE(7) FWD_CASE(8)
@@ -228,7 +231,7 @@ extern "C" int uwu_add_ln_modulate_fwd(const void* x_in, const void* y, const fl
 extern "C" int uwu_add_ln_modulate_bwd(const void* dh, const void* x, const float* mean, const float* rstd,
                                        const float* scale, const void* dx_in, const void* y, const float* gate,
                                        int mod_ld, void* dx_out, void* dy, float* dshift, float* dscale, float* dgate,
-                                       int B, int T, int D, int dtype, void* stream) {
+                                       int B, int T, int D, int affine, int dtype, void* stream) {
   UWU_CHECK_ARG(dh && x && mean && rstd && dx_out, "add_ln_modulate_bwd: null pointer");
   UWU_CHECK_ARG(B > 0 && T > 0 && D > 0 && D % 4 == 0 && D <= MAX_D, "add_ln_modulate_bwd: D=%d unsupported", D);
   UWU_CHECK_ARG((y == nullptr) || (gate && dy), "add_ln_modulate_bwd: y needs gate and dy");
@@ -245,12 +248,12 @@ extern "C" int uwu_add_ln_modulate_bwd(const void* dh, const void* x, const floa
     if (dtype == UWU_F32)                                                                                           \
       hipLaunchKernelGGL((add_ln_mod_bwd_kernel<float, NIT>), dim3(M / rows), dim3(256), lds, st, (const float*)dh, \
                          (const float*)x, mean, rstd, scale, (const float*)dx_in, (const float*)y, gate, mod_ld,    \
-                         (float*)dx_out, (float*)dy, dshift, dscale, dgate, M, T, D, rows);                         \
+                         (float*)dx_out, (float*)dy, dshift, dscale, dgate, M, T, D, rows, affine);                         \
     else                                                                                                            \
       hipLaunchKernelGGL((add_ln_mod_bwd_kernel<bf16_t, NIT>), dim3(M / rows), dim3(256), lds, st,                  \
                          (const bf16_t*)dh, (const bf16_t*)x, mean, rstd, scale, (const bf16_t*)dx_in,              \
                          (const bf16_t*)y, gate, mod_ld, (bf16_t*)dx_out, (bf16_t*)dy, dshift, dscale, dgate, M, T, \
-                         D, rows);                                                                                  \
+                         D, rows, affine);                                                                                  \
     break;
   switch ((D + 255) / 256) {
     BWD_CASE(1) BWD_CASE(2) BWD_CASE(3) BWD_CASE(4) BWD_CASE(5) BWD_CASE(6)
@@ -262,29 +265,40 @@ extern "C" int uwu_add_ln_modulate_bwd(const void* dh, const void* x, const floa
   return UWU_OK;
 }
 
+static int colsum_impl(const void* X, int dtype, int batch, int M, int N, int ldx, float* out, int accumulate,
+                       void* stream);
 extern "C" int uwu_colsum(const void* X, int dtype, int M, int N, int ldx, float* out, int accumulate, void* stream) {
-  UWU_CHECK_ARG(X && out && M > 0 && N > 0 && N % 4 == 0 && ldx % 4 == 0 && ldx >= N, "colsum: bad args (N=%d ldx=%d)", N,
-                ldx);
+  return colsum_impl(X, dtype, 1, M, N, ldx, out, accumulate, stream);
+}
+// out[b, n] (+)= sum_m X[b, m, n] for `batch` contiguous [M, ldx] slabs (per-sample reductions)
+extern "C" int uwu_colsum_batched(const void* X, int dtype, int batch, int M, int N, int ldx, float* out,
+                                  int accumulate, void* stream) {
+  return colsum_impl(X, dtype, batch, M, N, ldx, out, accumulate, stream);
+}
+static int colsum_impl(const void* X, int dtype, int batch, int M, int N, int ldx, float* out, int accumulate,
+                       void* stream) {
+  UWU_CHECK_ARG(X && out && batch > 0 && M > 0 && N > 0 && N % 4 == 0 && ldx % 4 == 0 && ldx >= N,
+                "colsum: bad args (N=%d ldx=%d)", N, ldx);
   hipStream_t st = (hipStream_t)stream;
   if (!accumulate) {
-    if (hipMemsetAsync(out, 0, (size_t)N * sizeof(float), st) != hipSuccess) {
+    if (hipMemsetAsync(out, 0, (size_t)batch * N * sizeof(float), st) != hipSuccess) {
       uwu_set_error("colsum: memset failed");
       return UWU_ELAUNCH;
     }
   }
   int splits = (M + 255) / 256;
   const int strips = (N + 63) / 64;
-  int want = 1024 / strips;
+  int want = 1024 / (strips * batch);
   if (want < 1) want = 1;
   if (splits > want) splits = want;
   const int rows = (M + splits - 1) / splits;
   splits = (M + rows - 1) / rows;
   if (dtype == UWU_F32)
-    hipLaunchKernelGGL((colsum_kernel<float>), dim3(strips, splits), dim3(256), 0, st, (const float*)X, M, N, ldx, out,
-                       rows);
-  else if (dtype == UWU_BF16)
-    hipLaunchKernelGGL((colsum_kernel<bf16_t>), dim3(strips, splits), dim3(256), 0, st, (const bf16_t*)X, M, N, ldx,
+    hipLaunchKernelGGL((colsum_kernel<float>), dim3(strips, splits, batch), dim3(256), 0, st, (const float*)X, M, N, ldx,
                        out, rows);
+  else if (dtype == UWU_BF16)
+    hipLaunchKernelGGL((colsum_kernel<bf16_t>), dim3(strips, splits, batch), dim3(256), 0, st, (const bf16_t*)X, M, N,
+                       ldx, out, rows);
   else
     UWU_CHECK_ARG(false, "colsum: bad dtype");
   UWU_LAUNCH_CHECK("colsum");

@@ -52,8 +52,9 @@ _SIGS = {
     "uwu_gemm_prof_enable": (c_int, [c_int]),
     "uwu_gemm_prof_collect": (c_int, [c_int, P, P, P]),
     "uwu_colsum": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, P]),
-    "uwu_add_ln_modulate_fwd": (c_int, [P, P, P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_float, c_int, P]),
-    "uwu_add_ln_modulate_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "uwu_colsum_batched": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, P]),
+    "uwu_add_ln_modulate_fwd": (c_int, [P, P, P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_float, c_int, c_int, P]),
+    "uwu_add_ln_modulate_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "uwu_attention_fwd": (c_int, [P, P, P, P, P] + [c_int] * 9 + [c_float, c_int, P]),
     "uwu_attention_bwd": (c_int, [P] * 10 + [c_int] * 9 + [c_float, c_int, P]),
     "uwu_timestep_embedding": (c_int, [P, c_int, c_int, c_float, P, c_int, P]),
@@ -63,6 +64,16 @@ _SIGS = {
     "uwu_patchify": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "uwu_unpatchify": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     "uwu_add_pos": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "uwu_groupnorm_fwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_int, c_int, P]),
+    "uwu_groupnorm_bwd": (c_int, [P] * 9 + [c_int] * 6 + [P]),
+    "uwu_im2col3x3": (c_int, [P, P] + [c_int] * 6 + [P]),
+    "uwu_col2im3x3": (c_int, [P, P] + [c_int] * 6 + [P]),
+    "uwu_geglu_fwd": (c_int, [P, P, c_int64, c_int, c_int, P]),
+    "uwu_geglu_bwd": (c_int, [P, P, P, c_int64, c_int, c_int, P]),
+    "uwu_upsample2x": (c_int, [P, P] + [c_int] * 6 + [P]),
+    "uwu_add_rowvec": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "uwu_nchw_to_cl": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "uwu_cl_to_nchw": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "uwu_dit_workspace_bytes": (c_size_t, [ctypes.POINTER(DitDesc)]),
     "uwu_dit_forward": (c_int, [ctypes.POINTER(DitDesc), P, P, P, P, P]),
     "uwu_dit_backward": (c_int, [ctypes.POINTER(DitDesc), P, P]),

@@ -24,25 +24,25 @@ def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, aux=None, epilogue=L.
     return (out, out2) if out2 is not None else out
 
 
-def add_ln_modulate_fwd(x_in, B, T, *, y=None, gate=None, shift=None, scale=None, mod_ld=0, eps=1e-6):
+def add_ln_modulate_fwd(x_in, B, T, *, y=None, gate=None, shift=None, scale=None, mod_ld=0, eps=1e-6, affine=False):
     M, D = x_in.shape
     x_out = torch.empty_like(x_in) if y is not None else x_in
     h = torch.empty_like(x_in)
     mean = torch.empty(M, device=x_in.device, dtype=torch.float32)
     rstd = torch.empty_like(mean)
     L.call("uwu_add_ln_modulate_fwd", L.ptr(x_in), L.ptr(y), _p(gate), _p(shift), _p(scale), mod_ld, L.ptr(x_out),
-           L.ptr(h), L.ptr(mean), L.ptr(rstd), B, T, D, eps, L.dt(x_in), L.stream())
+           L.ptr(h), L.ptr(mean), L.ptr(rstd), B, T, D, eps, int(affine), L.dt(x_in), L.stream())
     return x_out, h, mean, rstd
 
 
 def add_ln_modulate_bwd(dh, x, mean, rstd, B, T, *, scale=None, dx_in=None, y=None, gate=None, mod_ld=0,
-                        dshift=None, dscale=None, dgate=None):
+                        dshift=None, dscale=None, dgate=None, affine=False):
     M, D = x.shape
     dx = torch.empty_like(x)
     dy = torch.empty_like(x) if y is not None else None
     L.call("uwu_add_ln_modulate_bwd", L.ptr(dh), L.ptr(x), L.ptr(mean), L.ptr(rstd), _p(scale), L.ptr(dx_in),
-           L.ptr(y), _p(gate), mod_ld, L.ptr(dx), L.ptr(dy), _p(dshift), _p(dscale), _p(dgate), B, T, D, L.dt(x),
-           L.stream())
+           L.ptr(y), _p(gate), mod_ld, L.ptr(dx), L.ptr(dy), _p(dshift), _p(dscale), _p(dgate), B, T, D, int(affine),
+           L.dt(x), L.stream())
     return dx, dy
 
 
@@ -78,4 +78,97 @@ def colsum(x, out=None, accumulate=False):
     if out is None:
         out = torch.empty(N, device=x.device, dtype=torch.float32)
     L.call("uwu_colsum", L.ptr(x), L.dt(x), M, N, x.stride(0), L.ptr(out), int(accumulate), L.stream())
+    return out
+
+
+def colsum_batched(x, batch, M, N):
+    """x: contiguous [batch*M, N] -> fp32 [batch, N] per-slab column sums."""
+    out = torch.empty(batch, N, device=x.device, dtype=torch.float32)
+    L.call("uwu_colsum_batched", L.ptr(x), L.dt(x), batch, M, N, N, L.ptr(out), 0, L.stream())
+    return out
+
+
+def im2col3x3(x, B, H, W, C, stride=1):
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    col = torch.empty(B * Ho * Wo, 9 * C, device=x.device, dtype=x.dtype)
+    L.call("uwu_im2col3x3", L.ptr(x), L.ptr(col), B, H, W, C, stride, L.dt(x), L.stream())
+    return col
+
+
+def col2im3x3(dcol, B, H, W, C, stride=1):
+    dx = torch.empty(B * H * W, C, device=dcol.device, dtype=dcol.dtype)
+    L.call("uwu_col2im3x3", L.ptr(dcol), L.ptr(dx), B, H, W, C, stride, L.dt(dcol), L.stream())
+    return dx
+
+
+def groupnorm_fwd(x, gamma, beta, B, HW, C, G, eps, silu):
+    y = torch.empty_like(x)
+    mean = torch.empty(B * G, device=x.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    L.call("uwu_groupnorm_fwd", L.ptr(x), _p(gamma), _p(beta), L.ptr(y), L.ptr(mean), L.ptr(rstd), B, HW, C, G,
+           float(eps), int(silu), L.dt(x), L.stream())
+    return y, mean, rstd
+
+
+def groupnorm_bwd(dy, x, mean, rstd, gamma, beta, dgamma, dbeta, B, HW, C, G, silu):
+    dx = torch.empty_like(x)
+    L.call("uwu_groupnorm_bwd", L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), _p(gamma), _p(beta), L.ptr(dx),
+           _p(dgamma), _p(dbeta), B, HW, C, G, int(silu), L.dt(x), L.stream())
+    return dx
+
+
+def geglu_fwd(hg):
+    M, F2 = hg.shape
+    out = torch.empty(M, F2 // 2, device=hg.device, dtype=hg.dtype)
+    L.call("uwu_geglu_fwd", L.ptr(hg), L.ptr(out), M, F2 // 2, L.dt(hg), L.stream())
+    return out
+
+
+def geglu_bwd(hg, dout):
+    dhg = torch.empty_like(hg)
+    L.call("uwu_geglu_bwd", L.ptr(hg), L.ptr(dout), L.ptr(dhg), hg.shape[0], hg.shape[1] // 2, L.dt(hg), L.stream())
+    return dhg
+
+
+def silu_fwd(x):
+    y = torch.empty_like(x)
+    L.call("uwu_silu_fwd", L.ptr(x), L.ptr(y), x.numel(), L.dt(x), L.stream())
+    return y
+
+
+def silu_bwd(x, dy):
+    dx = torch.empty_like(x)
+    L.call("uwu_silu_bwd", L.ptr(x), L.ptr(dy), L.ptr(dx), x.numel(), L.dt(x), L.stream())
+    return dx
+
+
+def add(a, b):
+    out = torch.empty_like(a)
+    L.call("uwu_add", L.ptr(a.contiguous()), L.ptr(b.contiguous()), L.ptr(out), a.numel(), L.dt(a), L.stream())
+    return out
+
+
+def add_rowvec(x, v, B, HW, C):
+    out = x.clone()
+    L.call("uwu_add_rowvec", L.ptr(out), L.ptr(v.contiguous()), B, HW, C, L.dt(x), L.stream())
+    return out
+
+
+def upsample2x(x, B, H, W, C, backward=False):
+    n = B * H * W if backward else B * 4 * H * W
+    out = torch.empty(n, C, device=x.device, dtype=x.dtype)
+    L.call("uwu_upsample2x", L.ptr(x), L.ptr(out), B, H, W, C, int(backward), L.dt(x), L.stream())
+    return out
+
+
+def nchw_to_cl(x, dtype):
+    B, C, H, W = x.shape
+    out = torch.empty(B * H * W, C, device=x.device, dtype=dtype)
+    L.call("uwu_nchw_to_cl", L.ptr(x), L.ptr(out), B, C, H * W, L.dt(out), L.stream())
+    return out
+
+
+def cl_to_nchw(x, B, C, HW):
+    out = torch.empty(B, C, HW, device=x.device, dtype=torch.float32)
+    L.call("uwu_cl_to_nchw", L.ptr(x), L.ptr(out), B, C, HW, L.dt(x), L.stream())
     return out
