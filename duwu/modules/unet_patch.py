@@ -1,12 +1,16 @@
 """reference src/duwu/modules/unet_patch.py: the denoiser slot ``UNet2DFromScratch.from_config``.
 
-``config`` may be a preset name or a dict.  DiT presets ("DiT-S/2", "DiT-B/2", "DiT-L/2", "DiT-XL/2") build the
-MI355X-native DiT (uwudiff_amd/dit.py).  Hub names are never fetched: the SDXL UNet name used by the reference's
-own YAMLs is recognised and reported as not yet available on the HIP path (SURVEY.md section 8f ranks it "next").
+``config`` may be a preset name or a dict; hub names are resolved to built-in config dicts, nothing is fetched:
+  * "stabilityai/stable-diffusion-xl-base-1.0" (+ ``subfolder: unet``) -> the SDXL-shape UNet2DConditionModel
+    (uwudiff_amd/unet.py; what both of the reference's own training YAMLs instantiate);
+  * "tiny-unet" -> the small UNet of BASELINE.json configs[0];
+  * "DiT-S/2" | "DiT-B/2" | "DiT-L/2" | "DiT-XL/2" -> the MI355X-native DiT (uwudiff_amd/dit.py).
+The near-zero init of residual-branch output layers (unet_patch.py:34-45) is applied by the model constructors.
 """
 from uwudiff_amd.dit import PRESETS, DiT
+from uwudiff_amd.unet import UNet2DConditionModel
 
-_HUB_UNETS = {"stabilityai/stable-diffusion-xl-base-1.0", "runwayml/stable-diffusion-v1-5"}
+_UNET_NAMES = {"stabilityai/stable-diffusion-xl-base-1.0", "sdxl", "tiny-unet"}
 
 
 class UNet2DFromScratch:
@@ -15,13 +19,12 @@ class UNet2DFromScratch:
         if isinstance(config, str):
             if config in PRESETS:
                 return DiT.from_config(config, **kwargs)
-            if config in _HUB_UNETS:
-                raise NotImplementedError(
-                    f"{config!r} (SDXL-shape UNet2DConditionModel) has no HIP implementation yet in this build; "
-                    "use a DiT preset (e.g. config: DiT-S/2).  No hub access is attempted.")
-            raise ValueError(f"unknown denoiser config {config!r}")
+            if config in _UNET_NAMES:
+                return UNet2DConditionModel.from_config(config, **kwargs)
+            raise ValueError(f"unknown denoiser config {config!r} (offline registry: "
+                             f"{sorted(PRESETS) + sorted(_UNET_NAMES)})")
         cfg = dict(config)
-        kind = cfg.pop("architecture", "dit")
-        if kind != "dit":
-            raise NotImplementedError(f"architecture {kind!r}")
-        return DiT.from_config(cfg, **kwargs)
+        kind = cfg.pop("architecture", "unet" if "block_out_channels" in cfg else "dit")
+        if kind == "dit":
+            return DiT.from_config(cfg, **kwargs)
+        return UNet2DConditionModel.from_config(cfg, **kwargs)

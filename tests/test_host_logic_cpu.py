@@ -96,13 +96,20 @@ def test_reference_configs_parse_when_present():
     ref = "/root/reference/configs/demo_training_latent.yaml"
     if not os.path.exists(ref):
         pytest.skip("reference tree not present on this machine")
-    from duwu.loader import load_all
     from uwudiff_amd.config import load_yaml
 
     cfg = load_yaml(ref)
     assert cfg.seed == 1215 and cfg.data.dataloader_config.batch_size == 16
-    with pytest.raises(NotImplementedError):
-        load_all(cfg)
+    u = cfg.trainer.model_config.unet
+    assert u["_target_"] == "duwu.modules.unet_patch.UNet2DFromScratch.from_config"
+    # the hub id resolves to the built-in SDXL UNet config (2.57 B parameters: not instantiated in a CPU test)
+    from uwudiff_amd.unet import SDXL_UNET_CONFIG, UNet2DConditionModel
+
+    assert u["config"] == "stabilityai/stable-diffusion-xl-base-1.0"
+    assert SDXL_UNET_CONFIG["block_out_channels"] == (320, 640, 1280)
+    import duwu.modules.unet_patch as up
+
+    assert u["config"] in up._UNET_NAMES and up.UNet2DConditionModel is UNet2DConditionModel
 
 
 def test_lr_schedules():

@@ -70,3 +70,22 @@ def test_loss_curve_matches_cpu_oracle(dtype, tol):
     lo, lg = torch.tensor(lo), torch.tensor(lg)
     assert lo[-1] < lo[0] * 0.9  # it actually trains
     assert ((lo - lg).abs() / lo).max().item() < tol, (lo, lg)
+
+
+def test_fit_tiny_unet_config_with_clip_and_snr():
+    """configs/demo_training.yaml (C1): tiny UNet, min-SNR + debias, gradient clipping, through the launcher path."""
+    from duwu.loader import load_all
+    from uwudiff_amd.config import load_yaml, merge
+    from uwudiff_amd.engine import Fitter, seed_everything
+    from uwudiff_amd.unet import UNet2DConditionModel
+
+    cfg = merge(load_yaml(os.path.join(ROOT, "configs", "demo_training.yaml")),
+                {"lightning_config": {"fast_dev_run": False, "max_steps": 4, "log_every_n_steps": 1}})
+    lc = dict(cfg["lightning_config"])
+    lc.pop("callbacks", None)
+    fit = Fitter(**lc)
+    dm, tr = load_all(cfg)
+    assert isinstance(tr.unet, UNet2DConditionModel)
+    seed_everything(cfg.seed)
+    hist = fit.fit(tr, dm)
+    assert fit.global_step == 4 and all(torch.isfinite(torch.tensor(h["loss"])) for h in hist)

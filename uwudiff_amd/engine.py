@@ -104,6 +104,8 @@ class Fitter:
     def fit(self, module, datamodule, ckpt_path=None):
         if hasattr(module.unet, "cfg"):
             module.unet.cfg.compute_dtype = self.compute_dtype
+            if hasattr(module.unet, "P"):
+                module.unet.P.bf16 = self.compute_dtype == "bf16"
         module.to(self.device)
         module._trainer = self
         datamodule.setup("fit")
