@@ -191,9 +191,16 @@ def main():
         if n.value:
             ach = fl.value / (ms.value * 1e-3) / 1e12
             peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_BF16_TFLOPS / 16
+            # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this
+            # same command, gfx950 corrections applied by tools/summarize_pmc.py); null if not collected
+            traffic = None
+            tj = os.path.join(ROOT, "profiles", "r01_pmc_gemm_traffic.json")
+            if args.dtype == "bf16" and B == 256 and os.path.exists(tj):
+                with open(tj) as f:
+                    traffic = round(json.load(f)["hbm_bytes_per_launch"])
             roof = {"bound": "mfma", "kernel": "gemm_kernel (bf16 v_mfma_f32_16x16x32; fwd+dgrad+wgrad launches)",
                     "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": None, "launches_per_step": n.value // n_prof,
+                    "traffic": traffic, "launches_per_step": n.value // n_prof,
                     "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
                     "gemm_ms_per_step": round(ms.value / n_prof, 3)}
     elif world > 1:
