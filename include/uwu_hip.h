@@ -44,7 +44,8 @@ extern "C" {
 #define UWU_EPI_NONE 0
 #define UWU_EPI_BIAS 1       /* C = A.B + bias[n]                                        */
 #define UWU_EPI_BIAS_GELU 2  /* C = A.B + bias ; C2 = gelu_tanh(C)   (fc1 forward)       */
-#define UWU_EPI_DGELU 3      /* C = (A.B) * gelu_tanh'(aux[m,n])     (fc2 dgrad -> dU)   */
+#define UWU_EPI_DGELU 3      /* C = (A.B) * gelu_tanh'(aux[m,n])     (fc2 dgrad -> dU); if C2 != NULL it is a
+                                float[N] receiving += column sums of C (fc1 bias gradient)              */
 #define UWU_EPI_BIAS_SILU 4  /* C = silu(A.B + bias)                 (timestep MLP)      */
 #define UWU_EPI_ACCUM 5      /* C += A.B  (fp32 C only; wgrad accumulation, split-K)     */
 
@@ -147,11 +148,12 @@ int uwu_add_ln_modulate_fwd(const void* x_in, const void* y, const float* gate, 
  *   dx_out = dx_in + LN_bwd(dh * (1+scale_b))        (dx_in may be NULL for the last norm)
  *   dy     = gate_b * dx_out                          (if y given)
  *   dshift_b += sum_t dh ; dscale_b += sum_t dh*xhat ; dgate_b += sum_t dx_out*y   (fp32 atomics)
+ *   dybias   += sum over ALL rows of dy  (optional: the bias gradient of the Linear that produced y)
  * dmod rows live in a zero-initialised [B, mod_ld] fp32 buffer. */
 int uwu_add_ln_modulate_bwd(const void* dh, const void* x, const float* mean, const float* rstd,
                             const float* scale, const void* dx_in, const void* y, const float* gate,
                             int mod_ld, void* dx_out, void* dy, float* dshift, float* dscale, float* dgate,
-                            int B, int T, int D, int affine, int dtype, void* stream);
+                            float* dybias, int B, int T, int D, int affine, int dtype, void* stream);
 
 /* ------------------------------------------------------------------ attention (a12) */
 

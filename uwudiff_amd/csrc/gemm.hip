@@ -296,6 +296,36 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmArgs g) {
       return v;
     };
     const bool two = epi == UWU_EPI_BIAS_GELU || epi == UWU_EPI_BIAS_SILU;
+    // UWU_EPI_DGELU with C2 != NULL: C2 is a float[N] that receives += the column sums of C (the bias gradient of
+    // the Linear whose pre-activation is `aux`), summed over this tile's rows in registers / lanes, then atomics
+    float* colsum = (epi == UWU_EPI_DGELU) ? reinterpret_cast<float*>(g.C2) : nullptr;
+    f32x4 csum[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) csum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto add_cs = [&](f32x4& acc_, const f32x4& v) {
+      if constexpr (sizeof(TC) == 2) {  // sum what the consumers read: the bf16-rounded values
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc_[e] += (float)(bf16_t)v[e];
+      } else {
+        acc_ = acc_ + v;
+      }
+    };
+    auto flush_cs = [&]() {
+      if (!colsum) return;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 v = csum[j];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += __shfl_xor(v[e], o, 64);
+        const int n = n0 + wn * 64 + 16 * j + 4 * fq;
+        if (fr == 0 && n < g.N) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) atomicAdd(colsum + n + e, v[e]);
+        }
+      }
+    };
     if constexpr (sizeof(TC) == 2) {
       // bf16 output: stores are instruction-bound (fp32 output of the same tile costs the same per store), so
       // pair lanes l and l^16 (column groups fq, fq^1) and swap half of two neighbouring 16-column subtiles:
@@ -315,6 +345,10 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmArgs g) {
             const bool oka = mok && na < g.N, okc = mok && nc < g.N;
             f32x4 v0 = oka ? finish(acc[i][2 * jp], m, na, s0) : acc[i][2 * jp];
             f32x4 v1 = okc ? finish(acc[i][2 * jp + 1], m, nc, s1) : acc[i][2 * jp + 1];
+            if (colsum) {
+              if (oka) add_cs(csum[2 * jp], v0);
+              if (okc) add_cs(csum[2 * jp + 1], v1);
+            }
             auto pack = [](const f32x4& v) {
               bf16x4 b = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
               return *reinterpret_cast<uint2*>(&b);
@@ -335,6 +369,7 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmArgs g) {
             if (two) exchange_store(C2, s0, s1);
           }
         }
+        flush_cs();
         return;
       }
     }
@@ -347,10 +382,12 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmArgs g) {
         if (m >= g.M || n >= g.N) continue;
         f32x4 second = {0.f, 0.f, 0.f, 0.f};
         f32x4 v = finish(acc[i][j], m, n, second);
+        if (colsum) add_cs(csum[j], v);
         store4(C + (int64_t)m * g.ldc + n, v);
         if (two) store4(C2 + (int64_t)m * g.ldc + n, second);
       }
     }
+    flush_cs();
   }
 }
 
@@ -478,7 +515,7 @@ extern "C" int uwu_gemm(const void* A, const void* B, void* C, void* C2, const f
   g.tiles_n = (N + BN - 1) / BN;
   // 16-byte epilogue stores need 8-column granularity and 16-byte aligned rows
   g.wide = (!acc && c_dtype == UWU_BF16 && N % 8 == 0 && ldc % 8 == 0 && ((uintptr_t)C & 15) == 0 &&
-            (C2 == nullptr || ((uintptr_t)C2 & 15) == 0)) ? 1 : 0;
+            (C2 == nullptr || epilogue == UWU_EPI_DGELU || ((uintptr_t)C2 & 15) == 0)) ? 1 : 0;
 
   const int ktiles = (K + bk - 1) / bk;
   int split = split_k < 1 ? 1 : split_k;

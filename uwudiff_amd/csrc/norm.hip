@@ -89,16 +89,16 @@ __global__ void __launch_bounds__(256) add_ln_mod_bwd_kernel(
     const T* __restrict__ dh, const T* __restrict__ x, const float* __restrict__ mean_i,
     const float* __restrict__ rstd_i, const float* __restrict__ scale, const T* __restrict__ dx_in,
     const T* __restrict__ y, const float* __restrict__ gate, int mod_ld, T* __restrict__ dx_out, T* __restrict__ dy,
-    float* __restrict__ dshift, float* __restrict__ dscale, float* __restrict__ dgate, int M, int T_tok, int D,
-    int rows_per_block, int affine) {
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][3][D]
+    float* __restrict__ dshift, float* __restrict__ dscale, float* __restrict__ dgate,
+    float* __restrict__ dybias, int M, int T_tok, int D, int rows_per_block, int affine) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][4][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nit = (D + 255) >> 8;
   const int row0 = blockIdx.x * rows_per_block;
   const int b = row0 / T_tok;
-  f32x4 a_sh[MAX_IT], a_sc[MAX_IT], a_g[MAX_IT];
+  f32x4 a_sh[MAX_IT], a_sc[MAX_IT], a_g[MAX_IT], a_dy[MAX_IT];
 #pragma unroll
-  for (int it = 0; it < MAX_IT; ++it) a_sh[it] = a_sc[it] = a_g[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < MAX_IT; ++it) a_sh[it] = a_sc[it] = a_g[it] = a_dy[it] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   for (int r = wave; r < rows_per_block; r += 4) {
     const int row = row0 + r;
@@ -140,15 +140,23 @@ __global__ void __launch_bounds__(256) add_ln_mod_bwd_kernel(
         store4(dx_out + off + d, dx);
         if (y) {
           f32x4 yv = load4(y + off + d), gv = load4(gate + (int64_t)b * mod_ld + d);
-          store4(dy + off + d, gv * dx);
+          f32x4 dyv = gv * dx;
+          if constexpr (sizeof(T) == 2) {  // sum what the consumer GEMMs will read (the rounded values)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) a_g[it][e] += dx[e] * yv[e];
+            for (int e = 0; e < 4; ++e) dyv[e] = (float)(bf16_t)dyv[e];
+          }
+          store4(dy + off + d, dyv);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            a_g[it][e] += dx[e] * yv[e];
+            a_dy[it][e] += dyv[e];
+          }
         }
       }
     }
   }
   // fold the 4 waves' column partials
-  float* mine = red + (int64_t)wave * 3 * D;
+  float* mine = red + (int64_t)wave * 4 * D;
 #pragma unroll
   for (int it = 0; it < MAX_IT; ++it) {
     const int d = it * 256 + lane * 4;
@@ -156,13 +164,18 @@ __global__ void __launch_bounds__(256) add_ln_mod_bwd_kernel(
       store4(mine + d, a_sh[it]);
       store4(mine + D + d, a_sc[it]);
       store4(mine + 2 * D + d, a_g[it]);
+      store4(mine + 3 * D + d, a_dy[it]);
     }
   }
   __syncthreads();
-  const int ncol = (y ? 3 : 2) * D;
+  const int ncol = (y ? 4 : 2) * D;
   for (int c = threadIdx.x; c < ncol; c += 256) {
-    float t = red[c] + red[3 * D + c] + red[6 * D + c] + red[9 * D + c];
+    float t = red[c] + red[4 * D + c] + red[8 * D + c] + red[12 * D + c];
     const int which = c / D, d = c - which * D;
+    if (which == 3) {  // bias gradient of the Linear that produced y: sum of dy over every row of the batch
+      if (dybias) atomicAdd(dybias + d, t);
+      continue;
+    }
     float* dst = which == 0 ? dshift : (which == 1 ? dscale : dgate);
     if (dst) atomicAdd(dst + (int64_t)b * mod_ld + d, t);
   }
@@ -231,7 +244,7 @@ extern "C" int uwu_add_ln_modulate_fwd(const void* x_in, const void* y, const fl
 extern "C" int uwu_add_ln_modulate_bwd(const void* dh, const void* x, const float* mean, const float* rstd,
                                        const float* scale, const void* dx_in, const void* y, const float* gate,
                                        int mod_ld, void* dx_out, void* dy, float* dshift, float* dscale, float* dgate,
-                                       int B, int T, int D, int affine, int dtype, void* stream) {
+                                       float* dybias, int B, int T, int D, int affine, int dtype, void* stream) {
   UWU_CHECK_ARG(dh && x && mean && rstd && dx_out, "add_ln_modulate_bwd: null pointer");
   UWU_CHECK_ARG(B > 0 && T > 0 && D > 0 && D % 4 == 0 && D <= MAX_D, "add_ln_modulate_bwd: D=%d unsupported", D);
   UWU_CHECK_ARG((y == nullptr) || (gate && dy), "add_ln_modulate_bwd: y needs gate and dy");
@@ -239,21 +252,31 @@ extern "C" int uwu_add_ln_modulate_bwd(const void* dh, const void* x, const floa
   int rows = 32;
   while (rows > 1 && T % rows) rows >>= 1;
   const int M = B * T;
-  const size_t lds = (size_t)4 * 3 * D * sizeof(float);
+  const size_t lds = (size_t)4 * 4 * D * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   UWU_CHECK_ARG(dtype == UWU_F32 || dtype == UWU_BF16, "add_ln_modulate_bwd: bad dtype");
-  UWU_CHECK_ARG(lds <= 64 * 1024, "add_ln_modulate_bwd: D=%d needs %zu B of LDS (> 64 KB)", D, lds);
+  UWU_CHECK_ARG(lds <= 160 * 1024, "add_ln_modulate_bwd: D=%d needs %zu B of LDS (> 160 KB)", D, lds);
 #define BWD_CASE(NIT)                                                                                               \
   case NIT:                                                                                                         \
+    if (lds > 64 * 1024) { /* above the default dynamic-LDS limit: raise it once per instantiation */              \
+      static bool done_f = false, done_b = false;                                                                   \
+      bool& done = dtype == UWU_F32 ? done_f : done_b;                                                              \
+      if (!done) {                                                                                                  \
+        const void* kf = dtype == UWU_F32 ? reinterpret_cast<const void*>(add_ln_mod_bwd_kernel<float, NIT>)        \
+                                          : reinterpret_cast<const void*>(add_ln_mod_bwd_kernel<bf16_t, NIT>);      \
+        (void)hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                      \
+        done = true;                                                                                                \
+      }                                                                                                             \
+    }                                                                                                               \
     if (dtype == UWU_F32)                                                                                           \
       hipLaunchKernelGGL((add_ln_mod_bwd_kernel<float, NIT>), dim3(M / rows), dim3(256), lds, st, (const float*)dh, \
                          (const float*)x, mean, rstd, scale, (const float*)dx_in, (const float*)y, gate, mod_ld,    \
-                         (float*)dx_out, (float*)dy, dshift, dscale, dgate, M, T, D, rows, affine);                         \
+                         (float*)dx_out, (float*)dy, dshift, dscale, dgate, dybias, M, T, D, rows, affine);                         \
     else                                                                                                            \
       hipLaunchKernelGGL((add_ln_mod_bwd_kernel<bf16_t, NIT>), dim3(M / rows), dim3(256), lds, st,                  \
                          (const bf16_t*)dh, (const bf16_t*)x, mean, rstd, scale, (const bf16_t*)dx_in,              \
-                         (const bf16_t*)y, gate, mod_ld, (bf16_t*)dx_out, (bf16_t*)dy, dshift, dscale, dgate, M, T, \
-                         D, rows, affine);                                                                                  \
+                         (const bf16_t*)y, gate, mod_ld, (bf16_t*)dx_out, (bf16_t*)dy, dshift, dscale, dgate, dybias,  \
+                         M, T, D, rows, affine);                                                                                  \
     break;
   switch ((D + 255) / 256) {
     BWD_CASE(1) BWD_CASE(2) BWD_CASE(3) BWD_CASE(4) BWD_CASE(5) BWD_CASE(6)
