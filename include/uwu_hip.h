@@ -169,6 +169,14 @@ int uwu_attention_bwd(const void* q, const void* k, const void* v, const void* o
                       const float* lse, float* delta, void* dq, void* dk, void* dv, int B, int Tq, int Tk, int H,
                       int d, int ldq, int ldk, int ldv, int ldo, float scale, int dtype, void* stream);
 
+/* Axial RoPE with learnable per-head log-frequencies, exactly as the reference writes it (src/duwu/modules/rope.py:
+ * 56-71, 83-108; applied to q and k at rope_unet.py:143-147).  x/y: [rows, ldx] token-major with H heads of width d;
+ * pos: fp32 [rows, 2] (h, w); fh/fw: fp32 [H, d/4].  bwd: dx, and (optional) dfh/dfw += gradient wrt log-freqs. */
+int uwu_axial_rope_fwd(const void* x, const float* pos, const float* fh, const float* fw, void* y, int64_t rows,
+                       int H, int d, int ldx, int dtype, void* stream);
+int uwu_axial_rope_bwd(const void* x, const void* dy, const float* pos, const float* fh, const float* fw, void* dx,
+                       float* dfh, float* dfw, int64_t rows, int H, int d, int ldx, int dtype, void* stream);
+
 /* ------------------------------------------------------------------ embeddings / layout (a11, a13) */
 
 /* Sinusoidal timestep features [B, dim]: [cos(t*f_i) | sin(t*f_i)], f_i = exp(-ln(max_period)*i/half). */
