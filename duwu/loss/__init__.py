@@ -1,2 +1,3 @@
 """reference src/duwu/loss/__init__.py."""
-from uwudiff_amd.objective import DiffusionLoss, DiffusionLossAuxOutput, RectifiedFlowLoss  # noqa: F401
+from uwudiff_amd.objective import (DiffusionLoss, DiffusionLossAuxOutput, NNWeightedRFLoss,  # noqa: F401
+                                   NNWeightedRFLossAuxOutput, RectifiedFlowLoss)

@@ -127,6 +127,30 @@ def gen_rf(rmod, name, shape, seed, **kw):
          dloss_dout=out.grad)
 
 
+def gen_nnw(rmod, name, shape, seed, model_prediction_type="epsilon"):
+    """NNWeightedRFLoss.forward (rectified_flow.py:154-203) with the toy loss-prediction module of tests/golden_util.py."""
+    from tests.golden_util import ToyLossPred
+
+    B = shape[0]
+    torch.manual_seed(seed)
+    x, noise = torch.randn(shape), torch.randn(shape)
+    out = torch.randn(shape, requires_grad=True)
+    sched = EulerDiscreteScheduler.sdxl(prediction_type=model_prediction_type)
+    lp = ToyLossPred()
+    loss_mod = rmod.NNWeightedRFLoss(loss_pred_module=lp, scheduler=sched)
+    unet = LeafUNet(out)
+    torch.manual_seed(seed + 1)
+    loss, aux = loss_mod(torch.stack([x, noise], dim=1), unet)
+    loss.backward()
+    torch.manual_seed(seed + 1)
+    u01 = torch.rand(B)
+    meta = dict(kind="nnw_rf", shape=list(shape), seed=seed, prediction_type=loss_mod.prediction_type)
+    save(name, meta, x=x, noise=noise, u01=u01, timesteps=aux.timesteps, model_output=out.detach(), noisy=aux.noisy_latent,
+         pred=aux.pred, target=aux.target, rf_losses=aux.losses, rescaled_losses=aux.rescaled_losses,
+         pred_losses=aux.pred_losses, loss_pred_losses=aux.loss_pred_losses, loss=loss.detach(), dloss_dout=out.grad,
+         grad_a=lp.a.grad, grad_b=lp.b.grad, grad_c=lp.c.grad)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     dmod, rmod = load_reference_loss()
@@ -153,6 +177,9 @@ def main():
     gen_diffusion(dmod, "dl_big_eps", big, 1215)
     gen_diffusion(dmod, "dl_big_eps_snr_debias", big, 1215, use_snr_weight=True, use_debiased_estimation=True)
     gen_rf(rmod, "rf_big_eps", big, 1215)
+
+    gen_nnw(rmod, "nnw_s0_eps", small, 0)
+    gen_nnw(rmod, "nnw_s1215_v", small, 1215, model_prediction_type="v_prediction")
 
     # sigma_to_timestep on 64 log-spaced sigmas in [1e-3, 20] (rectified_flow.py:98-129)
     rf = rmod.RectifiedFlowLoss(scheduler=EulerDiscreteScheduler.sdxl())

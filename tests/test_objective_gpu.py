@@ -171,3 +171,27 @@ def test_adamw_and_clip_vs_torch():
     close(pbf, ref.data.bfloat16().float(), rtol=8e-3, atol=1e-6)
     close(m, opt.state[ref]["exp_avg"], rtol=1e-5, atol=1e-7)
     close(v, opt.state[ref]["exp_avg_sq"], rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("name", names("nnw_"))
+def test_nn_weighted_rf_loss_vs_reference_golden(name):
+    """reference rectified_flow.py:144-203 (NNWeightedRFLoss) run in-container -> tests/golden/nnw_*.npz."""
+    from tests.golden_util import ToyLossPred
+    from uwudiff_amd.objective import NNWeightedRFLoss
+
+    meta, d = load(name)
+    lp = ToyLossPred().cuda()
+    mod = NNWeightedRFLoss(loss_pred_module=lp, scheduler=_sched(prediction_type=meta["prediction_type"]))
+    out = d["model_output"].cuda().requires_grad_(True)
+    mod.inject(u01=d["u01"].cuda())
+    loss, aux = mod(torch.stack([d["x"], d["noise"]], dim=1).cuda(), LeafUNet(out))
+    loss.backward()
+    close(aux.noisy_latent, d["noisy"], rtol=1e-4, atol=1e-5)
+    close(aux.losses, d["rf_losses"], rtol=2e-4, atol=1e-7)
+    close(aux.pred_losses, d["pred_losses"], rtol=2e-4, atol=1e-7)
+    close(aux.rescaled_losses, d["rescaled_losses"], rtol=3e-4, atol=1e-7)
+    close(aux.loss_pred_losses, d["loss_pred_losses"], rtol=2e-3, atol=1e-6)
+    close(loss, d["loss"], rtol=3e-4, atol=1e-7)
+    close(out.grad, d["dloss_dout"], rtol=6e-4, atol=1e-7)
+    for k, p in (("grad_a", lp.a), ("grad_b", lp.b), ("grad_c", lp.c)):
+        close(p.grad, d[k], rtol=2e-3, atol=1e-5)

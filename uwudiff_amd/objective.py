@@ -239,3 +239,49 @@ class RectifiedFlowLoss(DiffusionLoss):
         aux = DiffusionLossAuxOutput(losses=losses, timesteps=timesteps, pred=pred, target=target,
                                      noisy_latent=noisy)
         return loss, aux
+
+
+class NNWeightedRFLossAuxOutput(NamedTuple):
+    losses: torch.Tensor
+    rescaled_losses: torch.Tensor
+    pred_losses: torch.Tensor
+    loss_pred_losses: torch.Tensor
+    timesteps: torch.Tensor
+    pred: torch.Tensor
+    target: torch.Tensor
+    noisy_latent: torch.Tensor
+
+
+class NNWeightedRFLoss(RectifiedFlowLoss):
+    """reference src/duwu/loss/rectified_flow.py:144-203: a second network predicts the log of the per-sample RF loss;
+    ``losses = rf / exp(s_hat).clamp(1e-4) + (log rf - s_hat)^2``.
+
+    The denoiser-side term ``rf_b / pred_loss_b`` is the fused loss kernel with ``1/pred_loss_b`` in its per-sample
+    weight slot (so the gradient wrt the model output comes out of the same single pass); the ``[B]``-sized
+    log/square tail and the gradient into ``loss_pred_module`` stay in autograd."""
+
+    def __init__(self, loss_pred_module: nn.Module, **kwargs):
+        super().__init__(**kwargs)
+        self.loss_pred_module = loss_pred_module
+
+    def forward(self, x: torch.Tensor, unet: nn.Module, **unet_kwargs):
+        pt = self._type_id(self.prediction_type, "prediction")
+        x, noises = self.get_x0_and_noises(x)
+        timesteps, coef = self.sample_timesteps_and_sigmas(x)
+        self._inject = None
+        noisy = self._qsample(x, noises, coef)
+        model_output = unet(noisy, timesteps, **unet_kwargs)[0]
+        sigmas = coef[:, 0]
+        log_ls_pred = self.loss_pred_module(noisy, sigmas, **unet_kwargs).flatten()  # takes sigmas (:180-183)
+        pred_loss = log_ls_pred.detach().exp().clamp(min=1e-4)
+        coef_w = coef.clone()
+        coef_w[:, 1] = 1.0 / pred_loss
+        rescaled_mean, rescaled, pred, target = _FusedLoss.apply(model_output, x, noises, noisy, coef_w,
+                                                                 pt, L.PT["rectified_flow"], True)
+        rf_losses = rescaled * pred_loss
+        ls_pred_loss = (rf_losses.log() - log_ls_pred).square()
+        loss = rescaled_mean + ls_pred_loss.mean()
+        aux = NNWeightedRFLossAuxOutput(losses=rf_losses, rescaled_losses=rescaled, pred_losses=pred_loss,
+                                        loss_pred_losses=ls_pred_loss, timesteps=timesteps, pred=pred, target=target,
+                                        noisy_latent=noisy)
+        return loss, aux
