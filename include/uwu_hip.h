@@ -89,6 +89,16 @@ int uwu_loss_fwd_bwd(const float* x, const float* noise, const float* xt, const 
 /* y[i] *= *scale (device scalar); used when autograd hands a non-unit upstream gradient. */
 int uwu_scale_inplace(void* y, int dtype, int64_t n, const float* scale, void* stream);
 
+/* Sampler (section 8f rank 1).  One Euler-ancestral step with classifier-free guidance, fused:
+ *   eps = uncond + (cond-uncond)*cfg  (reference sampling/cfg.py:113-125; eps_uncond NULL -> no guidance)
+ *   denoised = x - sigma*eps          (sampling/k_diffusion_wrapper.py:98-108)
+ *   x' = x + eps*(sigma_down - sigma) + noise*s_noise*sigma_up   (sampling/k_diffusion_euler.py:42-47)
+ * denoised may be NULL.  uwu_scale_copy: y = x*scale (the c_in = 1/sqrt(sigma^2+1) input scaling). */
+int uwu_sampler_step(const float* x, const float* eps_cond, const float* eps_uncond, const float* noise, float* out,
+                     float* denoised, int64_t n, float cfg, float sigma, float sigma_down, float sigma_up,
+                     float s_noise, void* stream);
+int uwu_scale_copy(const float* x, float* y, int64_t n, float scale, void* stream);
+
 /* ------------------------------------------------------------------ optimizer (a15) */
 
 /* Global L2 norm of a flat fp32 buffer (Lightning gradient_clip_val, demo_training.yaml:12):

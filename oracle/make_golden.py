@@ -186,6 +186,21 @@ def main():
     sig = torch.logspace(-3, np.log10(20.0), 64)
     save("sigma_to_timestep", dict(kind="sigma_to_timestep"), sigmas=sig, timesteps=rf.sigma_to_timestep(sig))
 
+    # sampling schedule helpers (section 8f rank 1): k_diffusion_wrapper.py and get_sigmas.py load by file path
+    kd = {}
+    for nm, fn in (("kdw", "sampling/k_diffusion_wrapper.py"), ("gs", "sampling/get_sigmas.py")):
+        spec = importlib.util.spec_from_file_location("_ref_" + nm, os.path.join(REF, fn))
+        kd[nm] = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(kd[nm])
+    abar = EulerDiscreteScheduler.sdxl().alphas_cumprod
+    ds = kd["kdw"].DiscreteSchedule(((1 - abar) / abar) ** 0.5, quantize=False)
+    probe = torch.logspace(-2, np.log10(20.0), 48)
+    tq = torch.tensor([0.0, 0.5, 17.25, 500.0, 998.75, 999.0])
+    save("kdiff_schedule", dict(kind="kdiff_schedule"), probe_sigmas=probe, sigma_to_t=ds.sigma_to_t(probe),
+         t_probe=tq, t_to_sigma=ds.t_to_sigma(tq), get_sigmas_20=ds.get_sigmas(20), get_sigmas_all=ds.get_sigmas(),
+         rf_sigmas_16=np.ascontiguousarray(kd["gs"].get_sigmas_for_rf(16, float(ds.sigma_max))).astype(np.float64),
+         rf_sigmas_8_min=np.ascontiguousarray(kd["gs"].get_sigmas_for_rf(8, 14.6146, 0.03)).astype(np.float64))
+
     # AxialRoPE(64, 4) forward (modules/rope.py:83-108) -- "next" row (f2), importable reference
     rope = load_reference_rope()
     torch.manual_seed(0)

@@ -1,0 +1,73 @@
+"""Oracle restatement of the reference sampling loop.  TEST INFRASTRUCTURE.
+
+  * ``DiscreteSchedule`` sigma<->t mapping: reference src/duwu/sampling/k_diffusion_wrapper.py:22-72 (importable by file
+    path -> goldens in tests/golden/kdiff_schedule.npz pin this restatement).
+  * ``get_sigmas_for_rf``: reference src/duwu/sampling/get_sigmas.py:6-18 (pure numpy, golden-pinned).
+  * ``to_d`` / ``get_ancestral_step``: third-party ``k_diffusion`` (absent, unpinned); published algorithm restated:
+        to_d = (x - denoised) / sigma
+        sigma_up = min(sigma_to, eta * sqrt(sigma_to^2 (sigma_from^2 - sigma_to^2) / sigma_from^2)); sigma_down = sqrt(sigma_to^2 - sigma_up^2)
+  * Euler-ancestral loop: reference src/duwu/sampling/k_diffusion_euler.py:8-48; CFG: sampling/cfg.py:113-125;
+    eps denoiser: k_diffusion_wrapper.py:75-108.
+"""
+import numpy as np
+import torch
+
+
+def sigmas_from_alphas_cumprod(abar):
+    return ((1 - abar) / abar) ** 0.5
+
+
+def sigma_to_t(log_sigmas, sigma):
+    log_sigma = sigma.log()
+    dists = log_sigma - log_sigmas[:, None]
+    low_idx = dists.ge(0).cumsum(dim=0).argmax(dim=0).clamp(max=log_sigmas.shape[0] - 2)
+    high_idx = low_idx + 1
+    low, high = log_sigmas[low_idx], log_sigmas[high_idx]
+    w = ((low - log_sigma) / (low - high)).clamp(0, 1)
+    return ((1 - w) * low_idx + w * high_idx).view(sigma.shape)
+
+
+def t_to_sigma(log_sigmas, t):
+    t = t.float()
+    low_idx, high_idx, w = t.floor().long(), t.ceil().long(), t.frac()
+    return ((1 - w) * log_sigmas[low_idx] + w * log_sigmas[high_idx]).exp()
+
+
+def get_sigmas(sigmas_table, n=None):
+    if n is None:
+        return torch.cat([sigmas_table.flip(0), sigmas_table.new_zeros([1])])
+    t = torch.linspace(len(sigmas_table) - 1, 0, n)
+    return torch.cat([t_to_sigma(sigmas_table.log(), t), sigmas_table.new_zeros([1])])
+
+
+def get_sigmas_for_rf(num_steps, max_sigma, min_sigma=0):
+    max_time, min_time = max_sigma / (1 + max_sigma), min_sigma / (1 + min_sigma)
+    time = np.flip(np.linspace(min_time, max_time, num_steps + 1))
+    return time / (1 - time)
+
+
+def get_ancestral_step(sigma_from, sigma_to, eta=1.0):
+    if not eta:
+        return sigma_to, 0.0
+    sigma_up = min(sigma_to, eta * (sigma_to ** 2 * (sigma_from ** 2 - sigma_to ** 2) / sigma_from ** 2) ** 0.5)
+    return (sigma_to ** 2 - sigma_up ** 2) ** 0.5, sigma_up
+
+
+@torch.no_grad()
+def sample_euler_ancestral_cfg(unet, x, sigmas, log_sigmas, cond_kwargs, uncond_kwargs, cfg, noises, eta=1.0, s_noise=1.0):
+    """CPU loop: eps model, CFG over (cond, uncond) kwargs, injected per-step noises."""
+    B = x.shape[0]
+    for i in range(len(sigmas) - 1):
+        s = float(sigmas[i])
+        c_in = 1 / (s ** 2 + 1) ** 0.5
+        t = sigma_to_t(log_sigmas, torch.full((B,), s))
+        eps_c = unet(x * c_in, t, **cond_kwargs)[0]
+        eps_u = unet(x * c_in, t, **uncond_kwargs)[0]
+        eps = eps_u + (eps_c - eps_u) * cfg
+        denoised = x - s * eps
+        sd, su = get_ancestral_step(s, float(sigmas[i + 1]), eta)
+        d = (x - denoised) / s
+        x = x + d * (sd - s)
+        if float(sigmas[i + 1]) > 0:
+            x = x + noises[i] * s_noise * su
+    return x

@@ -197,6 +197,39 @@ __global__ void scale_inplace_kernel(T* __restrict__ y, int64_t n4, const float*
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Sampler step: classifier-free guidance combine (reference sampling/cfg.py:113-125),
+// eps-denoiser (k_diffusion_wrapper.py:98-108: denoised = x - sigma*eps) and the Euler-ancestral update
+// (k_diffusion_euler.py:42-47 with k-diffusion's to_d / get_ancestral_step) fused into one pass:
+//   eps = uncond + (cond - uncond)*cfg ;  d = (x - denoised)/sigma = eps ;
+//   x' = x + d*(sigma_down - sigma) + noise * s_noise * sigma_up
+__global__ void sampler_step_kernel(const float* __restrict__ x, const float* __restrict__ eps_c,
+                                    const float* __restrict__ eps_u, const float* __restrict__ noise,
+                                    float* __restrict__ out, float* __restrict__ denoised, int64_t n4, float cfg,
+                                    float sigma, float sigma_down, float sigma_up_noise) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 xv = load4(x + 4 * i), c = load4(eps_c + 4 * i);
+    f32x4 u = eps_u ? load4(eps_u + 4 * i) : c;
+    f32x4 nz = noise ? load4(noise + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 o, dn;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float eps = u[e] + (c[e] - u[e]) * cfg;
+      dn[e] = xv[e] - sigma * eps;
+      const float d = (xv[e] - dn[e]) / sigma;
+      o[e] = xv[e] + d * (sigma_down - sigma) + nz[e] * sigma_up_noise;
+    }
+    store4(out + 4 * i, o);
+    if (denoised) store4(denoised + 4 * i, dn);
+  }
+}
+
+__global__ void scale_copy_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n4, float s) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) store4(y + 4 * i, load4(x + 4 * i) * s);
+}
+
 // ------------------------------------------------------------------------------- C ABI
 
 extern "C" int uwu_schedule_gather(const int64_t* timesteps, const float* sigmas_desc, const float* all_snr,
@@ -271,5 +304,22 @@ extern "C" int uwu_scale_inplace(void* y, int dtype, int64_t n, const float* sca
     hipLaunchKernelGGL((scale_inplace_kernel<bf16_t>), dim3(ew_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream,
                        (bf16_t*)y, n / 4, scale);
   UWU_LAUNCH_CHECK("scale_inplace");
+  return UWU_OK;
+}
+
+extern "C" int uwu_sampler_step(const float* x, const float* eps_cond, const float* eps_uncond, const float* noise,
+                                float* out, float* denoised, int64_t n, float cfg, float sigma, float sigma_down,
+                                float sigma_up, float s_noise, void* stream) {
+  UWU_CHECK_ARG(x && eps_cond && out && n > 0 && n % 4 == 0 && sigma > 0.f, "sampler_step: bad args");
+  hipLaunchKernelGGL(sampler_step_kernel, dim3(ew_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, eps_cond,
+                     eps_uncond, noise, out, denoised, n / 4, cfg, sigma, sigma_down, sigma_up * s_noise);
+  UWU_LAUNCH_CHECK("sampler_step");
+  return UWU_OK;
+}
+
+extern "C" int uwu_scale_copy(const float* x, float* y, int64_t n, float scale, void* stream) {
+  UWU_CHECK_ARG(x && y && n > 0 && n % 4 == 0, "scale_copy: bad args");
+  hipLaunchKernelGGL(scale_copy_kernel, dim3(ew_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n / 4, scale);
+  UWU_LAUNCH_CHECK("scale_copy");
   return UWU_OK;
 }
