@@ -158,12 +158,11 @@ int uwu_add_ln_modulate_fwd(const void* x_in, const void* y, const float* gate, 
  *   dx_out = dx_in + LN_bwd(dh * (1+scale_b))        (dx_in may be NULL for the last norm)
  *   dy     = gate_b * dx_out                          (if y given)
  *   dshift_b += sum_t dh ; dscale_b += sum_t dh*xhat ; dgate_b += sum_t dx_out*y   (fp32 atomics)
- *   dybias   += sum over ALL rows of dy  (optional: the bias gradient of the Linear that produced y)
  * dmod rows live in a zero-initialised [B, mod_ld] fp32 buffer. */
 int uwu_add_ln_modulate_bwd(const void* dh, const void* x, const float* mean, const float* rstd,
                             const float* scale, const void* dx_in, const void* y, const float* gate,
                             int mod_ld, void* dx_out, void* dy, float* dshift, float* dscale, float* dgate,
-                            float* dybias, int B, int T, int D, int affine, int dtype, void* stream);
+                            int B, int T, int D, int affine, int dtype, void* stream);
 
 /* ------------------------------------------------------------------ attention (a12) */
 

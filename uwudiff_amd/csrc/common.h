@@ -83,6 +83,30 @@ __device__ __forceinline__ void store4(bf16_t* p, f32x4 v) {
   *reinterpret_cast<bf16x4*>(p) = o;
 }
 
+// 8 consecutive elements as fp32 (one 16-byte access for bf16)
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x8 load8(const float* p) {
+  f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+  return f32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+__device__ __forceinline__ f32x8 load8(const bf16_t* p) {
+  bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+  f32x8 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r[i] = (float)v[i];
+  return r;
+}
+__device__ __forceinline__ void store8(float* p, f32x8 v) {
+  *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+  *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
+__device__ __forceinline__ void store8(bf16_t* p, f32x8 v) {
+  bf16x8 o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (bf16_t)v[i];
+  *reinterpret_cast<bf16x8*>(p) = o;
+}
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
 __device__ __forceinline__ float dsilu_f(float x) {
   float s = 1.f / (1.f + __expf(-x));

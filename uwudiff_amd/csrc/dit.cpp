@@ -335,14 +335,15 @@ extern "C" int uwu_dit_backward(const uwu_dit_desc* dp, const float* dout, void*
     // final LN bwd + gate bwd of the last MLP branch: dx = d/d x1_{L-1}; dy = gate_mlp * dx
     RUN(uwu_add_ln_modulate_bwd(P.at(L.dh), P.at(L.xF), P.at<float>(L.mF), P.at<float>(L.rF), mf + D, nullptr,
                                 P.lay(l, L.o_y2), mp + 5 * D, ML, P.at(L.dx), P.at(L.dy), dmf + 0, dmf + D, dmp + 5 * D,
-                                g + layer_weights(d, l).off_fc2_b, B, T, D, 0, dt, st));
+                                B, T, D, 0, dt, st));
   }
   for (int l = d.L - 1; l >= 0; --l) {
     const LayerW w = layer_weights(d, l);
     const float* m = mod + (int64_t)l * 6 * D;
     float* dm = dmod + (int64_t)l * 6 * D;
     // ---- MLP branch: y2 = fc2(gelu(fc1(h2)))
-    RUN(lin_wgrad(P.at(L.dy), P.lay(l, L.o_f), g + w.off_fc2_w, M, D, D4, dt, st));  // fc2.bias: fused in the LN bwd
+    RUN(lin_wgrad(P.at(L.dy), P.lay(l, L.o_f), g + w.off_fc2_w, M, D, D4, dt, st));
+    RUN(uwu_colsum(P.at(L.dy), dt, M, D, D, g + w.off_fc2_b, 1, st));
     // du = (dy.W2) * gelu'(u); the epilogue also accumulates colsum(du) = fc1.bias gradient
     RUN(lin_dgrad(P.at(L.dy), w.fc2_w, P.at(L.du), P.lay(l, L.o_u), M, D, D4, dt, st, g + w.off_fc1_b));
     RUN(lin_wgrad(P.at(L.du), P.lay(l, L.o_h2), g + w.off_fc1_w, M, D4, D, dt, st));
@@ -350,9 +351,10 @@ extern "C" int uwu_dit_backward(const uwu_dit_desc* dp, const float* dout, void*
     // LN2 bwd (+ residual) and gate bwd of the attention branch
     RUN(uwu_add_ln_modulate_bwd(P.at(L.dh), P.lay(l, L.o_x1), P.lay<float>(l, L.o_m2), P.lay<float>(l, L.o_r2), m + 4 * D,
                                 P.at(L.dx), P.lay(l, L.o_y1), m + 2 * D, ML, P.at(L.dx), P.at(L.dy), dm + 3 * D,
-                                dm + 4 * D, dm + 2 * D, g + w.off_o_b, B, T, D, 0, dt, st));
+                                dm + 4 * D, dm + 2 * D, B, T, D, 0, dt, st));
     // ---- attention branch: y1 = proj(attn(qkv(h1)))
-    RUN(lin_wgrad(P.at(L.dy), P.lay(l, L.o_ao), g + w.off_o_w, M, D, D, dt, st));  // proj.bias: fused in the LN2 bwd
+    RUN(lin_wgrad(P.at(L.dy), P.lay(l, L.o_ao), g + w.off_o_w, M, D, D, dt, st));
+    RUN(uwu_colsum(P.at(L.dy), dt, M, D, D, g + w.off_o_b, 1, st));
     RUN(lin_dgrad(P.at(L.dy), w.o_w, P.at(L.dao), nullptr, M, D, D, dt, st));
     char* qkv = P.lay<char>(l, L.o_qkv);
     char* dqkv = P.at<char>(L.dqkv);
@@ -368,10 +370,10 @@ extern "C" int uwu_dit_backward(const uwu_dit_desc* dp, const float* dout, void*
       float* dmp = dmod + (int64_t)(l - 1) * 6 * D;
       RUN(uwu_add_ln_modulate_bwd(P.at(L.dh), P.lay(l, L.o_x0), P.lay<float>(l, L.o_m1), P.lay<float>(l, L.o_r1), m + D,
                                   P.at(L.dx), P.lay(l - 1, L.o_y2), mp + 5 * D, ML, P.at(L.dx), P.at(L.dy), dm + 0,
-                                  dm + D, dmp + 5 * D, g + layer_weights(d, l - 1).off_fc2_b, B, T, D, 0, dt, st));
+                                  dm + D, dmp + 5 * D, B, T, D, 0, dt, st));
     } else {
       RUN(uwu_add_ln_modulate_bwd(P.at(L.dh), P.lay(l, L.o_x0), P.lay<float>(l, L.o_m1), P.lay<float>(l, L.o_r1), m + D,
-                                  P.at(L.dx), nullptr, nullptr, ML, P.at(L.dx), nullptr, dm + 0, dm + D, nullptr, nullptr, B, T, D, 0, dt, st));
+                                  P.at(L.dx), nullptr, nullptr, ML, P.at(L.dx), nullptr, dm + 0, dm + D, nullptr, B, T, D, 0, dt, st));
     }
   }
   // ---- patch embedding (input latents need no gradient; positions are fixed)

@@ -6,7 +6,7 @@
 
 namespace {
 
-constexpr int MAX_D = 2048;  // NIT = ceil(D/256) <= 8 (template parameter: keeps the register arrays exact)
+constexpr int MAX_D = 4096;  // 16-byte vectors: 8 elements per lane, NIT = ceil(D/512) (template parameter)
 
 template <typename T, int MAX_IT>
 __global__ void __launch_bounds__(256) add_ln_mod_fwd_kernel(const T* __restrict__ x_in, const T* __restrict__ y,
@@ -17,41 +17,41 @@ __global__ void __launch_bounds__(256) add_ln_mod_fwd_kernel(const T* __restrict
                                                              float* __restrict__ mean_o, float* __restrict__ rstd_o,
                                                              int M, int T_tok, int D, float eps, int affine) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nit = (D + 255) >> 8;
+  const int nit = (D + 511) >> 9;
   for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
     const int b = row / T_tok;
     const int64_t off = (int64_t)row * D;
-    f32x4 v[MAX_IT];
+    f32x8 v[MAX_IT];
     float s = 0.f;
 #pragma unroll
     for (int it = 0; it < MAX_IT; ++it) {
-      const int d = it * 256 + lane * 4;
+      const int d = it * 512 + lane * 8;
       if (it < nit && d < D) {
-        f32x4 xv = load4(x_in + off + d);
+        f32x8 xv = load8(x_in + off + d);
         if (y) {
-          f32x4 yv = load4(y + off + d), gv = load4(gate + (int64_t)b * mod_ld + d);
+          f32x8 yv = load8(y + off + d), gv = load8(gate + (int64_t)b * mod_ld + d);
           xv = xv + gv * yv;
           // keep the stored residual stream and the normalised value consistent in reduced precision
           if constexpr (sizeof(T) == 2) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) xv[e] = (float)(bf16_t)xv[e];
+            for (int e = 0; e < 8; ++e) xv[e] = (float)(bf16_t)xv[e];
           }
-          store4(x_out + off + d, xv);
+          store8(x_out + off + d, xv);
         }
         v[it] = xv;
-        s += xv[0] + xv[1] + xv[2] + xv[3];
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) s += xv[e];
       } else {
-        v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        v[it] = f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       }
     }
     const float mean = wave_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
     for (int it = 0; it < MAX_IT; ++it) {
-      const int d = it * 256 + lane * 4;
+      const int d = it * 512 + lane * 8;
       if (it < nit && d < D) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 8; ++e) {
           float c = v[it][e] - mean;
           q += c * c;
         }
@@ -65,17 +65,17 @@ __global__ void __launch_bounds__(256) add_ln_mod_fwd_kernel(const T* __restrict
     }
 #pragma unroll
     for (int it = 0; it < MAX_IT; ++it) {
-      const int d = it * 256 + lane * 4;
+      const int d = it * 512 + lane * 8;
       if (it < nit && d < D) {
-        f32x4 o;
+        f32x8 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (v[it][e] - mean) * rstd;
+        for (int e = 0; e < 8; ++e) o[e] = (v[it][e] - mean) * rstd;
         if (scale) {
-          f32x4 sc = load4(scale + (int64_t)b * mod_ld + d), sh = load4(shift + (int64_t)b * mod_ld + d);
+          f32x8 sc = load8(scale + (int64_t)b * mod_ld + d), sh = load8(shift + (int64_t)b * mod_ld + d);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = o[e] * (affine ? sc[e] : 1.f + sc[e]) + sh[e];
+          for (int e = 0; e < 8; ++e) o[e] = o[e] * (affine ? sc[e] : 1.f + sc[e]) + sh[e];
         }
-        store4(h + off + d, o);
+        store8(h + off + d, o);
       }
     }
   }
@@ -89,33 +89,33 @@ __global__ void __launch_bounds__(256) add_ln_mod_bwd_kernel(
     const T* __restrict__ dh, const T* __restrict__ x, const float* __restrict__ mean_i,
     const float* __restrict__ rstd_i, const float* __restrict__ scale, const T* __restrict__ dx_in,
     const T* __restrict__ y, const float* __restrict__ gate, int mod_ld, T* __restrict__ dx_out, T* __restrict__ dy,
-    float* __restrict__ dshift, float* __restrict__ dscale, float* __restrict__ dgate,
-    float* __restrict__ dybias, int M, int T_tok, int D, int rows_per_block, int affine) {
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][4][D]
+    float* __restrict__ dshift, float* __restrict__ dscale, float* __restrict__ dgate, int M, int T_tok, int D,
+    int rows_per_block, int affine) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][3][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nit = (D + 255) >> 8;
+  const int nit = (D + 511) >> 9;
   const int row0 = blockIdx.x * rows_per_block;
   const int b = row0 / T_tok;
-  f32x4 a_sh[MAX_IT], a_sc[MAX_IT], a_g[MAX_IT], a_dy[MAX_IT];
+  f32x8 a_sh[MAX_IT], a_sc[MAX_IT], a_g[MAX_IT];
 #pragma unroll
-  for (int it = 0; it < MAX_IT; ++it) a_sh[it] = a_sc[it] = a_g[it] = a_dy[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < MAX_IT; ++it) a_sh[it] = a_sc[it] = a_g[it] = f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   for (int r = wave; r < rows_per_block; r += 4) {
     const int row = row0 + r;
     if (row >= M) break;
     const int64_t off = (int64_t)row * D;
     const float mean = mean_i[row], rstd = rstd_i[row];
-    f32x4 xh[MAX_IT], g[MAX_IT];
+    f32x8 xh[MAX_IT], g[MAX_IT];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int it = 0; it < MAX_IT; ++it) {
-      const int d = it * 256 + lane * 4;
+      const int d = it * 512 + lane * 8;
       if (it < nit && d < D) {
-        f32x4 xv = load4(x + off + d), dv = load4(dh + off + d);
-        f32x4 sc = scale ? load4(scale + (int64_t)b * mod_ld + d)
-                         : (affine ? f32x4{1.f, 1.f, 1.f, 1.f} : f32x4{0.f, 0.f, 0.f, 0.f});
+        f32x8 xv = load8(x + off + d), dv = load8(dh + off + d);
+        f32x8 sc = scale ? load8(scale + (int64_t)b * mod_ld + d)
+                         : (affine ? f32x8{1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f} : f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 8; ++e) {
           float xhat = (xv[e] - mean) * rstd;
           float gg = dv[e] * (affine ? sc[e] : 1.f + sc[e]);
           xh[it][e] = xhat;
@@ -131,51 +131,38 @@ __global__ void __launch_bounds__(256) add_ln_mod_bwd_kernel(
     s2 = wave_sum(s2) / (float)D;
 #pragma unroll
     for (int it = 0; it < MAX_IT; ++it) {
-      const int d = it * 256 + lane * 4;
+      const int d = it * 512 + lane * 8;
       if (it < nit && d < D) {
-        f32x4 dx;
+        f32x8 dx;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dx[e] = rstd * (g[it][e] - s1 - xh[it][e] * s2);
-        if (dx_in) dx = dx + load4(dx_in + off + d);
-        store4(dx_out + off + d, dx);
+        for (int e = 0; e < 8; ++e) dx[e] = rstd * (g[it][e] - s1 - xh[it][e] * s2);
+        if (dx_in) dx = dx + load8(dx_in + off + d);
+        store8(dx_out + off + d, dx);
         if (y) {
-          f32x4 yv = load4(y + off + d), gv = load4(gate + (int64_t)b * mod_ld + d);
-          f32x4 dyv = gv * dx;
-          if constexpr (sizeof(T) == 2) {  // sum what the consumer GEMMs will read (the rounded values)
+          f32x8 yv = load8(y + off + d), gv = load8(gate + (int64_t)b * mod_ld + d);
+          store8(dy + off + d, gv * dx);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dyv[e] = (float)(bf16_t)dyv[e];
-          }
-          store4(dy + off + d, dyv);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            a_g[it][e] += dx[e] * yv[e];
-            a_dy[it][e] += dyv[e];
-          }
+          for (int e = 0; e < 8; ++e) a_g[it][e] += dx[e] * yv[e];
         }
       }
     }
   }
   // fold the 4 waves' column partials
-  float* mine = red + (int64_t)wave * 4 * D;
+  float* mine = red + (int64_t)wave * 3 * D;
 #pragma unroll
   for (int it = 0; it < MAX_IT; ++it) {
-    const int d = it * 256 + lane * 4;
+    const int d = it * 512 + lane * 8;
     if (it < nit && d < D) {
-      store4(mine + d, a_sh[it]);
-      store4(mine + D + d, a_sc[it]);
-      store4(mine + 2 * D + d, a_g[it]);
-      store4(mine + 3 * D + d, a_dy[it]);
+      store8(mine + d, a_sh[it]);
+      store8(mine + D + d, a_sc[it]);
+      store8(mine + 2 * D + d, a_g[it]);
     }
   }
   __syncthreads();
-  const int ncol = (y ? 4 : 2) * D;
+  const int ncol = (y ? 3 : 2) * D;
   for (int c = threadIdx.x; c < ncol; c += 256) {
-    float t = red[c] + red[4 * D + c] + red[8 * D + c] + red[12 * D + c];
+    float t = red[c] + red[3 * D + c] + red[6 * D + c] + red[9 * D + c];
     const int which = c / D, d = c - which * D;
-    if (which == 3) {  // bias gradient of the Linear that produced y: sum of dy over every row of the batch
-      if (dybias) atomicAdd(dybias + d, t);
-      continue;
-    }
     float* dst = which == 0 ? dshift : (which == 1 ? dscale : dgate);
     if (dst) atomicAdd(dst + (int64_t)b * mod_ld + d, t);
   }
@@ -213,10 +200,11 @@ extern "C" int uwu_add_ln_modulate_fwd(const void* x_in, const void* y, const fl
                                        const float* scale, int mod_ld, void* x_out, void* h, float* mean, float* rstd,
                                        int B, int T, int D, float eps, int affine, int dtype, void* stream) {
   UWU_CHECK_ARG(x_in && h && mean && rstd, "add_ln_modulate_fwd: null pointer");
-  UWU_CHECK_ARG(B > 0 && T > 0 && D > 0 && D % 4 == 0 && D <= MAX_D, "add_ln_modulate_fwd: D=%d unsupported", D);
+  UWU_CHECK_ARG(B > 0 && T > 0 && D > 0 && D % 8 == 0 && D <= MAX_D, "add_ln_modulate_fwd: D=%d unsupported", D);
   UWU_CHECK_ARG((y == nullptr) || (gate && x_out), "add_ln_modulate_fwd: y needs gate and x_out");
   UWU_CHECK_ARG((scale == nullptr) == (shift == nullptr), "add_ln_modulate_fwd: scale/shift go together");
   UWU_CHECK_ARG(!scale || mod_ld % 4 == 0, "add_ln_modulate_fwd: mod_ld must be a multiple of 4");
+  UWU_CHECK_ARG((((uintptr_t)x_in | (uintptr_t)h) & 15) == 0, "add_ln_modulate_fwd: tensors must be 16-byte aligned");
   const int M = B * T;
   int grid = (M + 3) / 4;
   if (grid > 8192) grid = 8192;
@@ -233,7 +221,7 @@ extern "C" int uwu_add_ln_modulate_fwd(const void* x_in, const void* y, const fl
                          (const bf16_t*)y, gate, shift, scale, mod_ld, (bf16_t*)x_out, (bf16_t*)h, mean, rstd, M,  \
                          T, D, eps, affine);                                                                               \
     break;
-  switch ((D + 255) / 256) {
+  switch ((D + 511) / 512) {
     FWD_CASE(1) FWD_CASE(2) FWD_CASE(3) FWD_CASE(4) FWD_CASE(5) FWD_CASE(6) FWD_CASE(7) FWD_CASE(8)
   }
 #undef FWD_CASE
@@ -244,15 +232,16 @@ extern "C" int uwu_add_ln_modulate_fwd(const void* x_in, const void* y, const fl
 extern "C" int uwu_add_ln_modulate_bwd(const void* dh, const void* x, const float* mean, const float* rstd,
                                        const float* scale, const void* dx_in, const void* y, const float* gate,
                                        int mod_ld, void* dx_out, void* dy, float* dshift, float* dscale, float* dgate,
-                                       float* dybias, int B, int T, int D, int affine, int dtype, void* stream) {
+                                       int B, int T, int D, int affine, int dtype, void* stream) {
   UWU_CHECK_ARG(dh && x && mean && rstd && dx_out, "add_ln_modulate_bwd: null pointer");
-  UWU_CHECK_ARG(B > 0 && T > 0 && D > 0 && D % 4 == 0 && D <= MAX_D, "add_ln_modulate_bwd: D=%d unsupported", D);
+  UWU_CHECK_ARG(B > 0 && T > 0 && D > 0 && D % 8 == 0 && D <= MAX_D, "add_ln_modulate_bwd: D=%d unsupported", D);
+  UWU_CHECK_ARG((((uintptr_t)dh | (uintptr_t)x | (uintptr_t)dx_out) & 15) == 0, "add_ln_modulate_bwd: tensors must be 16-byte aligned");
   UWU_CHECK_ARG((y == nullptr) || (gate && dy), "add_ln_modulate_bwd: y needs gate and dy");
   UWU_CHECK_ARG(!(scale || y) || mod_ld % 4 == 0, "add_ln_modulate_bwd: mod_ld must be a multiple of 4");
   int rows = 32;
   while (rows > 1 && T % rows) rows >>= 1;
   const int M = B * T;
-  const size_t lds = (size_t)4 * 4 * D * sizeof(float);
+  const size_t lds = (size_t)4 * 3 * D * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   UWU_CHECK_ARG(dtype == UWU_F32 || dtype == UWU_BF16, "add_ln_modulate_bwd: bad dtype");
   UWU_CHECK_ARG(lds <= 160 * 1024, "add_ln_modulate_bwd: D=%d needs %zu B of LDS (> 160 KB)", D, lds);
@@ -271,17 +260,17 @@ extern "C" int uwu_add_ln_modulate_bwd(const void* dh, const void* x, const floa
     if (dtype == UWU_F32)                                                                                           \
       hipLaunchKernelGGL((add_ln_mod_bwd_kernel<float, NIT>), dim3(M / rows), dim3(256), lds, st, (const float*)dh, \
                          (const float*)x, mean, rstd, scale, (const float*)dx_in, (const float*)y, gate, mod_ld,    \
-                         (float*)dx_out, (float*)dy, dshift, dscale, dgate, dybias, M, T, D, rows, affine);                         \
+                         (float*)dx_out, (float*)dy, dshift, dscale, dgate, M, T, D, rows, affine);                         \
     else                                                                                                            \
       hipLaunchKernelGGL((add_ln_mod_bwd_kernel<bf16_t, NIT>), dim3(M / rows), dim3(256), lds, st,                  \
                          (const bf16_t*)dh, (const bf16_t*)x, mean, rstd, scale, (const bf16_t*)dx_in,              \
-                         (const bf16_t*)y, gate, mod_ld, (bf16_t*)dx_out, (bf16_t*)dy, dshift, dscale, dgate, dybias,  \
-                         M, T, D, rows, affine);                                                                                  \
+                         (const bf16_t*)y, gate, mod_ld, (bf16_t*)dx_out, (bf16_t*)dy, dshift, dscale, dgate, M, T,   \
+                         D, rows, affine);                                                                                  \
     break;
-  switch ((D + 255) / 256) {
+  switch ((D + 511) / 512) {
     BWD_CASE(1) BWD_CASE(2) BWD_CASE(3) BWD_CASE(4) BWD_CASE(5) BWD_CASE(6)
     default:
-      UWU_CHECK_ARG(false, "add_ln_modulate_bwd: D=%d > 1536 not instantiated", D);
+      UWU_CHECK_ARG(false, "add_ln_modulate_bwd: D=%d > 3072 not instantiated", D);
   }
 #undef BWD_CASE
   UWU_LAUNCH_CHECK("add_ln_modulate_bwd");

@@ -36,13 +36,12 @@ def add_ln_modulate_fwd(x_in, B, T, *, y=None, gate=None, shift=None, scale=None
 
 
 def add_ln_modulate_bwd(dh, x, mean, rstd, B, T, *, scale=None, dx_in=None, y=None, gate=None, mod_ld=0,
-                        dshift=None, dscale=None, dgate=None, dybias=None, affine=False):
+                        dshift=None, dscale=None, dgate=None, affine=False):
     M, D = x.shape
     dx = torch.empty_like(x)
     dy = torch.empty_like(x) if y is not None else None
     L.call("uwu_add_ln_modulate_bwd", L.ptr(dh), L.ptr(x), L.ptr(mean), L.ptr(rstd), _p(scale), L.ptr(dx_in),
-           L.ptr(y), _p(gate), mod_ld, L.ptr(dx), L.ptr(dy), _p(dshift), _p(dscale), _p(dgate), _p(dybias), B, T, D,
-           int(affine),
+           L.ptr(y), _p(gate), mod_ld, L.ptr(dx), L.ptr(dy), _p(dshift), _p(dscale), _p(dgate), B, T, D, int(affine),
            L.dt(x), L.stream())
     return dx, dy
 
