@@ -22,7 +22,9 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 MODEL = "DiT-S/2"
-STEP_GFLOP_PER_IMG = 36.3   # BASELINE.md section 2 (3 x forward, no recompute)
+# step GFLOP per image (3 x forward, no recompute)
+STEP_GFLOP = {"DiT-S/2": 36.3, "DiT-B/2": 138.0, "DiT-L/2": 484.0, "DiT-XL/2": 711.7}
+DESC = {"DiT-S/2": "L12 D384 h6", "DiT-B/2": "L12 D768 h12", "DiT-L/2": "L24 D1024 h16", "DiT-XL/2": "L28 D1152 h16"}
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
 
 
@@ -84,6 +86,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--clip", type=float, default=0.0)
+    ap.add_argument("--model", default=MODEL, choices=sorted(STEP_GFLOP),
+                    help="DiT preset; the headline metric (BASELINE.json) is DiT-S/2, the others are extra configs")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL over xGMI) for real runs; gloo lets several ranks share ONE GPU to rehearse the "
                          "multi-process path on a 1-GPU box")
@@ -118,7 +122,7 @@ def main():
     B = args.batch
     torch.manual_seed(1215 + rank)  # configs/demo_training_latent.yaml:1 + test_train.py:69 (seed + rank)
     # random (non-zero) weights everywhere: zero-initialised gates would make whole branches numerically dead
-    model = DiT.from_config(MODEL, cond_dim=1280, init="random", compute_dtype=args.dtype).to(dev)
+    model = DiT.from_config(args.model, cond_dim=1280, init="random", compute_dtype=args.dtype).to(dev)
     if world > 1:  # identical replicas: broadcast rank 0's parameters
         dist.broadcast(model.flat.data, src=0)
         model.refresh_shadow()
@@ -156,7 +160,7 @@ def main():
         torch.cuda.synchronize()
 
     if rank == 0:
-        print(f"[bench] {MODEL} {args.dtype} per-GPU batch {B} x {world} GPU(s): warm-up {args.warmup}, timing {args.steps} steps",
+        print(f"[bench] {args.model} {args.dtype} per-GPU batch {B} x {world} GPU(s): warm-up {args.warmup}, timing {args.steps} steps",
               file=sys.stderr, flush=True)
     for _ in range(args.warmup):
         step()
@@ -195,7 +199,7 @@ def main():
             # same command, gfx950 corrections applied by tools/summarize_pmc.py); null if not collected
             traffic = None
             tj = os.path.join(ROOT, "profiles", "r01_pmc_gemm_traffic.json")
-            if args.dtype == "bf16" and B == 256 and os.path.exists(tj):
+            if args.dtype == "bf16" and B == 256 and args.model == MODEL and os.path.exists(tj):
                 with open(tj) as f:
                     traffic = round(json.load(f)["hbm_bytes_per_launch"])
             roof = {"bound": "mfma", "kernel": "gemm_kernel (bf16 v_mfma_f32_16x16x32; fwd+dgrad+wgrad launches)",
@@ -214,20 +218,20 @@ def main():
         imgs = B * world * args.steps
         value = imgs / elapsed
         line = {
-            "metric": "train images/sec (whole node), DiT-S/2 256^2 latent", "value": round(value, 1),
+            "metric": f"train images/sec (whole node), {args.model} 256^2 latent", "value": round(value, 1),
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{MODEL} (L12 D384 h6), 4x32x32 synthetic latents + pooled-text cond 1280, "
+            "config": {"workload": f"{args.model} ({DESC[args.model]}), 4x32x32 synthetic latents + pooled-text cond 1280, "
                                    f"eps-MSE, AdamW lr1e-6 wd0.01 cosine; random-init weights",
                        "per_gpu_batch": B, "global_batch": B * world, "tokens_per_image": 256,
                        "parallelism": f"dp{world}"},
-            "model_tflops": round(value * STEP_GFLOP_PER_IMG / 1e3, 1),
-            "mfma_frac_whole_step": round(value * STEP_GFLOP_PER_IMG / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
+            "model_tflops": round(value * STEP_GFLOP[args.model] / 1e3, 1),
+            "mfma_frac_whole_step": round(value * STEP_GFLOP[args.model] / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
             "final_loss": round(final_loss, 5),
             "roofline": roof,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.model == MODEL:
             line["cpu_baseline"] = cpu_baseline()
         else:
             line["cpu_baseline"] = None

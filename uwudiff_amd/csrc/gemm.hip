@@ -463,6 +463,12 @@ bool uwu_gemm_ring_ok(int K, int dtype);
 int uwu_gemm_ring(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux, int M, int N,
                   int K, int lda, int ldb, int ldc, int ldaux, int dtype, int c_dtype, int epilogue, hipStream_t st);
 
+// 256x384 panel kernel for the token-parallel bf16 Linears (gemm_panel.hip)
+bool uwu_gemm_panel_ok(int M, int N, int K, int lda, int ldb, int ldc, int ldaux, int dtype, int c_dtype, int epilogue,
+                       const void* A, const void* B, const void* C, const void* C2, const void* aux);
+int uwu_gemm_panel(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux, int M, int N,
+                   int K, int lda, int ldb, int ldc, int ldaux, int epilogue, hipStream_t st);
+
 extern "C" int uwu_gemm(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux, int M,
                         int N, int K, int lda, int ldb, int ldc, int ldaux, int transA, int transB, int dtype,
                         int c_dtype, int epilogue, int split_k, void* stream) {
@@ -494,6 +500,19 @@ extern "C" int uwu_gemm(const void* A, const void* B, void* C, void* C2, const f
                     "gemm: aux missing/misaligned");
   } else {
     UWU_CHECK_ARG(c_dtype == UWU_F32 && ldc >= N, "gemm: ACCUM needs fp32 C");
+  }
+  if (!transA && !transB && !acc &&
+      uwu_gemm_panel_ok(M, N, K, lda, ldb, ldc, ldaux, dtype, c_dtype, epilogue, A, B, C, C2, aux)) {
+    const bool rec = g_prof.on && g_prof.n < GemmProf::MAXP;
+    if (rec) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], (hipStream_t)stream);
+    int rc = uwu_gemm_panel(A, B, C, C2, bias, aux, M, N, K, lda, ldb, ldc, ldaux, epilogue, (hipStream_t)stream);
+    if (rec) {
+      (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], (hipStream_t)stream);
+      g_prof.flops[g_prof.n] = 2.0 * M * N * K;
+      g_prof.kind[g_prof.n] = 0;
+      ++g_prof.n;
+    }
+    return rc;
   }
   if (!transA && !transB && !acc && uwu_gemm_ring_ok(K, dtype)) {
     const bool rec = g_prof.on && g_prof.n < GemmProf::MAXP;
