@@ -130,6 +130,18 @@ int uwu_gemm(const void* A, const void* B, void* C, void* C2, const float* bias,
              int M, int N, int K, int lda, int ldb, int ldc, int ldaux, int transA, int transB, int dtype,
              int c_dtype, int epilogue, int split_k, void* stream);
 
+/* Weight gradient of a Linear with caller-provided split-K scratch:  C[M,N] (fp32) += A[K,M]^T . B[K,N], both
+ * operands K-major (A = dY [tokens, out], B = X [tokens, in]; reference: autograd of nn.Linear inside the blocks,
+ * rope_unet.py:122-166).  bf16 operands with K % 32 == 0 run the streaming kernel (LDS-DMA + transposing LDS
+ * reads, K split into a multiple of 8 slices, one group of slices per XCD); with `scratch` of at least
+ * uwu_gemm_wgrad_scratch_bytes(M, N, K) bytes the slices are written there and summed by a second kernel, with
+ * scratch == NULL they are accumulated with fp32 atomics.  Other shapes / fp32 operands are
+ * uwu_gemm(transA=1, transB=1, UWU_EPI_ACCUM) with `blocks` workgroups as the split-K target.
+ * Results differ only in summation order. */
+size_t uwu_gemm_wgrad_scratch_bytes(int M, int N, int K);
+int uwu_gemm_wgrad(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int dtype,
+                   int blocks, void* scratch, size_t scratch_bytes, void* stream);
+
 /* Live measurement for bench.py's `roofline` object: when enabled, every uwu_gemm launch is bracketed by a HIP
  * event pair recorded on that launch's stream; collect() returns the summed launch duration, the summed
  * algorithmic FLOPs (2*M*N*K) and the launch count for operand kind 0 (bf16) or 1 (fp32). */

@@ -117,3 +117,114 @@ def test_gemm_rejects_bad_shapes():
     b = torch.zeros(128, 66, device="cuda", dtype=torch.bfloat16)
     with pytest.raises(L.UwuError):
         ops.gemm(a, b)
+
+
+# ---- 256x128-tile kernel (gemm_r3_kernel): picked by the host for K-contiguous bf16 operands once there are >= 1024
+# tiles.  It issues the same sequence of 16x16x32 MFMAs per output as the 128x128 kernel, so the two must agree bit
+# for bit on any operands; UWU_GEMM_R3=0 (read per call) keeps a call on the 128x128 kernel, which the tests above
+# pin to the CPU fp64 matmul.
+R3_SHAPES = [(65536, 1152, 384), (52000, 648, 160), (262144, 128, 96), (33000, 1536, 1536)]
+
+
+def _both(monkeypatch, fn):
+    monkeypatch.setenv("UWU_GEMM_R3", "0")
+    ref = fn()
+    monkeypatch.setenv("UWU_GEMM_R3", "1")
+    return ref, fn()
+
+
+@pytest.mark.parametrize("M,N,K", R3_SHAPES)
+@pytest.mark.parametrize("c_dtype", [torch.bfloat16, torch.float32])
+def test_gemm_r3_matches_128_kernel(M, N, K, c_dtype, monkeypatch):
+    from uwudiff_amd import lib as L
+    from uwudiff_amd import ops
+
+    a, b = _operands(M, N, K, False, False, torch.bfloat16, ints=False, seed=7)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(8)).cuda()
+    ref, got = _both(monkeypatch, lambda: ops.gemm(a, b, c_dtype=c_dtype))
+    assert torch.equal(ref, got)
+    ref, got = _both(monkeypatch, lambda: ops.gemm(a, b, bias=bias, epilogue=L.EPI_BIAS, c_dtype=c_dtype))
+    assert torch.equal(ref, got)
+    if M * N <= 65536 * 1152:
+        (u0, f0), (u1, f1) = _both(monkeypatch, lambda: ops.gemm(a, b, bias=bias, epilogue=L.EPI_BIAS_GELU, c_dtype=c_dtype))
+        assert torch.equal(u0, u1) and torch.equal(f0, f1)
+
+
+def test_gemm_r3_exact_integers_and_dgelu(monkeypatch):
+    from uwudiff_amd import lib as L
+    from uwudiff_amd import ops
+
+    M, N, K = 65536, 1536, 384
+    a, b = _operands(M, N, K, False, False, torch.bfloat16, ints=True, seed=9)
+    monkeypatch.setenv("UWU_GEMM_R3", "1")
+    c = ops.gemm(a, b, c_dtype=torch.float32)
+    # exact on integers: compare with a torch fp32 matmul of the same (exactly representable) operands
+    want = a.float() @ b.float().t()
+    assert torch.equal(c, want)
+    u = (torch.randn(M, N, generator=torch.Generator().manual_seed(10)) * 1.5).bfloat16().cuda()
+
+    def run():
+        cs = torch.zeros(N, device="cuda")
+        out = ops.gemm(a, b, aux=u, epilogue=L.EPI_DGELU, out2=cs)
+        return (out[0] if isinstance(out, tuple) else out), cs
+
+    (d0, s0), (d1, s1) = _both(monkeypatch, run)
+    assert torch.equal(d0, d1)
+    torch.testing.assert_close(s0, s1, rtol=1e-4, atol=1.0)  # fp32 atomics: order differs
+
+
+# ---- K-major x K-major accumulate kernel (gemm_tr_kernel: LDS-DMA + ds_read_b64_tr_b16), used for the weight
+# gradients dW += dY^T X with split-K.  Integer operands make every partial sum exact, so the fp32 atomics are
+# order-independent and the result must equal both the exact matmul and the 128x128 kernel (UWU_GEMM_TR=0).
+TR_SHAPES = [(1536, 384, 65536, 14), (1152, 384, 8192, 7), (384, 1536, 4096, 3), (200, 264, 2048, 5), (768, 768, 2080, 1)]
+
+
+@pytest.mark.parametrize("M,N,K,split", TR_SHAPES)
+def test_gemm_tr_exact_integers(M, N, K, split, monkeypatch):
+    from uwudiff_amd import lib as L
+    from uwudiff_amd import ops
+
+    a, b = _operands(M, N, K, True, True, torch.bfloat16, ints=True, seed=11)
+
+    def run():
+        out = torch.ones(M, N, device="cuda")  # accumulate on top of existing content
+        ops.gemm(a, b, trans_a=True, trans_b=True, epilogue=L.EPI_ACCUM, out=out, split_k=split)
+        return out
+
+    monkeypatch.setenv("UWU_GEMM_TR", "0")
+    ref = run()
+    monkeypatch.setenv("UWU_GEMM_TR", "1")
+    got = run()
+    want = a.float().t() @ b.float() + 1.0
+    assert torch.equal(ref, want)
+    assert torch.equal(got, want)
+
+
+def test_gemm_tr_random(monkeypatch):
+    from uwudiff_amd import lib as L
+    from uwudiff_amd import ops
+
+    M, N, K = 1152, 384, 16384
+    a, b = _operands(M, N, K, True, True, torch.bfloat16, ints=False, seed=12)
+    monkeypatch.setenv("UWU_GEMM_TR", "1")
+    out = torch.zeros(M, N, device="cuda")
+    ops.gemm(a, b, trans_a=True, trans_b=True, epilogue=L.EPI_ACCUM, out=out, split_k=9)
+    want = (a.double().t() @ b.double()).float()
+    torch.testing.assert_close(out, want, rtol=1e-4, atol=2e-2)
+
+
+@pytest.mark.parametrize("M,N,K", [(1536, 384, 65536), (1152, 384, 8192), (384, 1536, 4096), (200, 264, 2048)])
+def test_gemm_wgrad_scratch_path(M, N, K):
+    """uwu_gemm_wgrad with split-K scratch (slices + reduce kernel) == exact matmul on integers, on top of existing C."""
+    from uwudiff_amd import ops
+
+    a, b = _operands(M, N, K, True, True, torch.bfloat16, ints=True, seed=13)
+    want = a.float().t() @ b.float() + 2.0
+    for scratch in (ops.gemm_wgrad_scratch(M, N, K), None):
+        dw = torch.full((M, N), 2.0, device="cuda")
+        ops.gemm_wgrad(a, b, dw, scratch=scratch)
+        assert torch.equal(dw, want)
+    # fp32 operands take the 128x128 kernel with atomics
+    dw = torch.zeros(M, N, device="cuda")
+    ops.gemm_wgrad(a.float(), b.float(), dw)
+    assert torch.equal(dw, want - 2.0)

@@ -53,15 +53,16 @@ def main():
             "fc2_dgrad": (M, 4 * D, D, 0, 1), "qkv_wgrad": (3 * D, D, M, 1, 1), "fc1_wgrad": (4 * D, D, M, 1, 1),
             "fc2_wgrad": (D, 4 * D, M, 1, 1), "proj_wgrad": (D, D, M, 1, 1),
         }.items():
+            if os.environ.get("UWU_BENCH_ONLY") and name not in os.environ["UWU_BENCH_ONLY"].split(","):
+                continue
             a = torch.randn((k, m) if ta else (m, k), device=dev).to(bf)
             b = torch.randn((k, n) if tb else (n, k), device=dev).to(bf)
             fl = 2.0 * m * n * k
             if ta:
                 out = torch.zeros(m, n, device=dev)
-                tiles = ((m + 127) // 128) * ((n + 127) // 128)
                 target = int(os.environ.get('UWU_WGRAD_BLOCKS', '512'))
-                split = max(1, min((target + tiles - 1) // tiles, (k + 63) // 64))
-                fn = lambda: ops.gemm(a, b, trans_a=True, trans_b=True, epilogue=L.EPI_ACCUM, out=out, split_k=split)
+                scratch = ops.gemm_wgrad_scratch(m, n, k) if os.environ.get('UWU_WGRAD_SCRATCH', '1') == '1' else None
+                fn = lambda: ops.gemm_wgrad(a, b, out, blocks=target, scratch=scratch)
             else:
                 out = torch.empty(m, n, device=dev, dtype=bf)
                 fn = lambda: ops.gemm(a, b, trans_a=False, trans_b=bool(tb), out=out)

@@ -36,6 +36,18 @@ __device__ __forceinline__ int swz(int row, int chunk) {
   return row * ROW_BYTES + (((chunk ^ (row >> 1) ^ (row >> 4)) & 7) << 4);
 }
 
+// Fragment read as inline asm for the LDS-DMA path: hipcc cannot prove that a compiler-visible ds_read does not
+// alias the in-flight DMA destination (the OTHER stage) and drains s_waitcnt vmcnt(0) in front of it, so the next
+// stage's load would never overlap this stage's MFMAs (PMC: waves parked 46 % of their cycles).  The dependency
+// on the DMA is carried by the explicit vmcnt(0) + barrier at the end of each K-step instead.
+typedef unsigned gu32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 lds_read128_asm(const char* p) {
+  gu32x4 v;
+  const unsigned a = (unsigned)(size_t)((const __attribute__((address_space(3))) char*)p);
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a) : "memory");
+  return uint4{v[0], v[1], v[2], v[3]};
+}
+
 // ---- staging: one 128-row x 128-byte operand tile per call, 256 threads ------------------------------
 template <typename T, bool TRANS>
 struct Stager {
@@ -163,6 +175,128 @@ struct GemmArgs {
   int M, N, K, lda, ldb, ldc, ldaux, epi, tiles_m, tiles_n, k_tiles_per_split, wide;
 };
 
+// Epilogue of one wave tile of FI x FJ 16x16 accumulators in the swapped-operand orientation (each lane owns 4
+// consecutive columns of one row): bias / GELU / dGELU(+column sums) math and 8- or 16-byte stores.
+// (m_w, n_w) = first row / column of the wave tile.
+template <typename T, typename TC, int FI, int FJ>
+__device__ __forceinline__ void epilogue_tile(f32x4 (&acc)[FI][FJ], const GemmArgs& g, int m_w, int n_w, int fr,
+                                              int fq) {
+  TC* C = static_cast<TC*>(g.C);
+  TC* C2 = static_cast<TC*>(g.C2);
+  const T* aux = static_cast<const T*>(g.aux);
+  const int epi = g.epi;
+  // per-subtile epilogue math on this lane's 4 consecutive columns
+  auto finish = [&](f32x4 v, int m, int n, f32x4& second) {
+    if (epi == UWU_EPI_BIAS || epi == UWU_EPI_BIAS_GELU || epi == UWU_EPI_BIAS_SILU) v = v + load4(g.bias + n);
+    if (epi == UWU_EPI_DGELU) {
+      f32x4 u = load4(aux + (int64_t)m * g.ldaux + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= dgelu_tanh_f(u[e]);
+    }
+    if (epi == UWU_EPI_BIAS_GELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) second[e] = gelu_tanh_f(v[e]);
+    } else if (epi == UWU_EPI_BIAS_SILU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) second[e] = silu_f(v[e]);
+    }
+    return v;
+  };
+  const bool two = epi == UWU_EPI_BIAS_GELU || epi == UWU_EPI_BIAS_SILU;
+  // UWU_EPI_DGELU with C2 != NULL: C2 is a float[N] that receives += the column sums of C (the bias gradient of
+  // the Linear whose pre-activation is `aux`), summed over this tile's rows in registers / lanes, then atomics
+  float* colsum = (epi == UWU_EPI_DGELU) ? reinterpret_cast<float*>(g.C2) : nullptr;
+  f32x4 csum[FJ];
+#pragma unroll
+  for (int j = 0; j < FJ; ++j) csum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto add_cs = [&](f32x4& acc_, const f32x4& v) {
+    if constexpr (sizeof(TC) == 2) {  // sum what the consumers read: the bf16-rounded values
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc_[e] += (float)(bf16_t)v[e];
+    } else {
+      acc_ = acc_ + v;
+    }
+  };
+  auto flush_cs = [&]() {
+    if (!colsum) return;
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) {
+      f32x4 v = csum[j];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += __shfl_xor(v[e], o, 64);
+      const int n = n_w + 16 * j + 4 * fq;
+      if (fr == 0 && n < g.N) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(colsum + n + e, v[e]);
+      }
+    }
+  };
+  if constexpr (sizeof(TC) == 2) {
+    // bf16 output: stores are instruction-bound (fp32 output of the same tile costs the same per store), so
+    // pair lanes l and l^16 (column groups fq, fq^1) and swap half of two neighbouring 16-column subtiles:
+    // even fq keeps subtile 2jp (own 4 columns + partner's next 4), odd fq keeps subtile 2jp+1 -> one 16-B store
+    // per lane covering 8 consecutive columns, 64 contiguous bytes per row per instruction, half the stores.
+    if (g.wide) {
+      const bool odd = fq & 1;
+#pragma unroll
+      for (int i = 0; i < FI; ++i) {
+        const int m = m_w + 16 * i + fr;
+        const bool mok = m < g.M;
+#pragma unroll
+        for (int jp = 0; jp < FJ / 2; ++jp) {
+          const int nb = n_w + 32 * jp;  // first column of subtile 2jp
+          f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+          const int na = nb + 4 * fq, nc = nb + 16 + 4 * fq;
+          const bool oka = mok && na < g.N, okc = mok && nc < g.N;
+          f32x4 v0 = oka ? finish(acc[i][2 * jp], m, na, s0) : acc[i][2 * jp];
+          f32x4 v1 = okc ? finish(acc[i][2 * jp + 1], m, nc, s1) : acc[i][2 * jp + 1];
+          if (colsum) {
+            if (oka) add_cs(csum[2 * jp], v0);
+            if (okc) add_cs(csum[2 * jp + 1], v1);
+          }
+          auto pack = [](const f32x4& v) {
+            bf16x4 b = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+            return *reinterpret_cast<uint2*>(&b);
+          };
+          auto exchange_store = [&](TC* dst, const f32x4& x0, const f32x4& x1) {
+            const uint2 p0 = pack(x0), p1 = pack(x1);
+            const uint2 send = odd ? p0 : p1;
+            uint2 recv;
+            recv.x = __shfl_xor(send.x, 16, 64);
+            recv.y = __shfl_xor(send.y, 16, 64);
+            const int n = odd ? nb + 16 + 4 * (fq - 1) : nb + 4 * fq;
+            if (mok && n < g.N) {
+              const uint4 o = odd ? uint4{recv.x, recv.y, p1.x, p1.y} : uint4{p0.x, p0.y, recv.x, recv.y};
+              *reinterpret_cast<uint4*>(dst + (int64_t)m * g.ldc + n) = o;
+            }
+          };
+          exchange_store(C, v0, v1);
+          if (two) exchange_store(C2, s0, s1);
+        }
+      }
+      flush_cs();
+      return;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < FI; ++i) {
+    const int m = m_w + 16 * i + fr;
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) {
+      const int n = n_w + 16 * j + 4 * fq;
+      if (m >= g.M || n >= g.N) continue;
+      f32x4 second = {0.f, 0.f, 0.f, 0.f};
+      f32x4 v = finish(acc[i][j], m, n, second);
+      if (colsum) add_cs(csum[j], v);
+      store4(C + (int64_t)m * g.ldc + n, v);
+      if (two) store4(C2 + (int64_t)m * g.ldc + n, second);
+    }
+  }
+  flush_cs();
+}
+
 // ACC = atomic-accumulate epilogue (standard accumulator orientation: registers walk rows, lanes walk
 // 16 consecutive columns -> 64-B atomic segments).  Otherwise the MFMA operands are swapped so that each lane
 // owns 4 consecutive columns of one row and can apply the epilogue on / store 8-16 B vectors directly.
@@ -230,6 +364,32 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmArgs g) {
         sb.load(B, g.ldb, n0, (kt + 1) * BK, g.N, g.K, tid);
       }
     }
+    if constexpr (GL) {
+      // both k-halves' fragments up front (two register sets); the MFMAs of half 0 run under the reads of half 1
+      uint4 af[2][4], bf[2][4];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[kk][i] = lds_read128_asm(la + swz(wm * 64 + 16 * i + fr, 4 * kk + fq));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[kk][j] = lds_read128_asm(lb + swz(wn * 64 + 16 * j + fr, 4 * kk + fq));
+        if (kk == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mma_frag<T>(bf[0][j], af[0][i], acc[i][j]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mma_frag<T>(bf[1][j], af[1][i], acc[i][j]);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next stage has landed (this wave's pieces)
+      __builtin_amdgcn_s_barrier();                     // ... everybody's; and everybody is done reading `cur`
+      continue;
+    }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       uint4 af[4], bf[4];
@@ -274,121 +434,293 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmArgs g) {
         }
       }
   } else {
-    TC* C = static_cast<TC*>(g.C);
-    TC* C2 = static_cast<TC*>(g.C2);
-    const T* aux = static_cast<const T*>(g.aux);
-    const int epi = g.epi;
-    // per-subtile epilogue math on this lane's 4 consecutive columns
-    auto finish = [&](f32x4 v, int m, int n, f32x4& second) {
-      if (epi == UWU_EPI_BIAS || epi == UWU_EPI_BIAS_GELU || epi == UWU_EPI_BIAS_SILU) v = v + load4(g.bias + n);
-      if (epi == UWU_EPI_DGELU) {
-        f32x4 u = load4(aux + (int64_t)m * g.ldaux + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= dgelu_tanh_f(u[e]);
-      }
-      if (epi == UWU_EPI_BIAS_GELU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) second[e] = gelu_tanh_f(v[e]);
-      } else if (epi == UWU_EPI_BIAS_SILU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) second[e] = silu_f(v[e]);
-      }
-      return v;
-    };
-    const bool two = epi == UWU_EPI_BIAS_GELU || epi == UWU_EPI_BIAS_SILU;
-    // UWU_EPI_DGELU with C2 != NULL: C2 is a float[N] that receives += the column sums of C (the bias gradient of
-    // the Linear whose pre-activation is `aux`), summed over this tile's rows in registers / lanes, then atomics
-    float* colsum = (epi == UWU_EPI_DGELU) ? reinterpret_cast<float*>(g.C2) : nullptr;
-    f32x4 csum[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) csum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto add_cs = [&](f32x4& acc_, const f32x4& v) {
-      if constexpr (sizeof(TC) == 2) {  // sum what the consumers read: the bf16-rounded values
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc_[e] += (float)(bf16_t)v[e];
-      } else {
-        acc_ = acc_ + v;
-      }
-    };
-    auto flush_cs = [&]() {
-      if (!colsum) return;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        f32x4 v = csum[j];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += __shfl_xor(v[e], o, 64);
-        const int n = n0 + wn * 64 + 16 * j + 4 * fq;
-        if (fr == 0 && n < g.N) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) atomicAdd(colsum + n + e, v[e]);
-        }
-      }
-    };
-    if constexpr (sizeof(TC) == 2) {
-      // bf16 output: stores are instruction-bound (fp32 output of the same tile costs the same per store), so
-      // pair lanes l and l^16 (column groups fq, fq^1) and swap half of two neighbouring 16-column subtiles:
-      // even fq keeps subtile 2jp (own 4 columns + partner's next 4), odd fq keeps subtile 2jp+1 -> one 16-B store
-      // per lane covering 8 consecutive columns, 64 contiguous bytes per row per instruction, half the stores.
-      if (g.wide) {
-        const bool odd = fq & 1;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int m = m0 + wm * 64 + 16 * i + fr;
-          const bool mok = m < g.M;
-#pragma unroll
-          for (int jp = 0; jp < 2; ++jp) {
-            const int nb = n0 + wn * 64 + 32 * jp;  // first column of subtile 2jp
-            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
-            const int na = nb + 4 * fq, nc = nb + 16 + 4 * fq;
-            const bool oka = mok && na < g.N, okc = mok && nc < g.N;
-            f32x4 v0 = oka ? finish(acc[i][2 * jp], m, na, s0) : acc[i][2 * jp];
-            f32x4 v1 = okc ? finish(acc[i][2 * jp + 1], m, nc, s1) : acc[i][2 * jp + 1];
-            if (colsum) {
-              if (oka) add_cs(csum[2 * jp], v0);
-              if (okc) add_cs(csum[2 * jp + 1], v1);
-            }
-            auto pack = [](const f32x4& v) {
-              bf16x4 b = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-              return *reinterpret_cast<uint2*>(&b);
-            };
-            auto exchange_store = [&](TC* dst, const f32x4& x0, const f32x4& x1) {
-              const uint2 p0 = pack(x0), p1 = pack(x1);
-              const uint2 send = odd ? p0 : p1;
-              uint2 recv;
-              recv.x = __shfl_xor(send.x, 16, 64);
-              recv.y = __shfl_xor(send.y, 16, 64);
-              const int n = odd ? nb + 16 + 4 * (fq - 1) : nb + 4 * fq;
-              if (mok && n < g.N) {
-                const uint4 o = odd ? uint4{recv.x, recv.y, p1.x, p1.y} : uint4{p0.x, p0.y, recv.x, recv.y};
-                *reinterpret_cast<uint4*>(dst + (int64_t)m * g.ldc + n) = o;
-              }
-            };
-            exchange_store(C, v0, v1);
-            if (two) exchange_store(C2, s0, s1);
-          }
-        }
-        flush_cs();
-        return;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0 + wm * 64 + 16 * i + fr;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn * 64 + 16 * j + 4 * fq;
-        if (m >= g.M || n >= g.N) continue;
-        f32x4 second = {0.f, 0.f, 0.f, 0.f};
-        f32x4 v = finish(acc[i][j], m, n, second);
-        if (colsum) add_cs(csum[j], v);
-        store4(C + (int64_t)m * g.ldc + n, v);
-        if (two) store4(C2 + (int64_t)m * g.ldc + n, second);
-      }
-    }
-    flush_cs();
+    epilogue_tile<T, TC, 4, 4>(acc, g, m0 + wm * 64, n0 + wn * 64, fr, fq);
   }
+}
+
+// ---- 256x128-tile kernel for the token-parallel Linears (K-contiguous bf16 operands) --------------------------
+// PMC on the 128x128 kernel (65536x1152x384): the L2 -> LDS intake (903 MB per launch at ~12 TB/s chip-wide) is the
+// longest phase and the waves are parked 46 % of their cycles on the 2-stage pipeline.  Same two-workgroups-per-CU
+// structure (independent barriers: one workgroup's MFMAs run under the other's waits, and tile ends / store bursts
+// stagger by themselves), but: 256x128 tile (85 flop per L2 byte instead of 64), K-step 32 = 64-byte rows, a
+// 3-stage LDS-DMA ring (2 x 24 KB in flight per workgroup, 72 KB -> two workgroups per CU), counted vmcnt waits, one
+// barrier per K-step, fragment reads as inline asm (see lds_read128_asm).
+// Wave tile 128x64 = 8x4 accumulators of v_mfma_f32_16x16x32_bf16; LDS image [A rows 0..255 | B rows 0..127] x 64 B
+// with 16-byte chunk c of row r at position c ^ G[(r>>2)&3], G = {0,3,2,1} (conflict-free in the four ds_read_b128
+// lane groups); the DMA writes lane-linear, so the swizzle is applied to the per-lane source address.
+constexpr int R_BM = 256, R_BN = 128, R_ROWB = 64, R_NST = 3;
+constexpr int R_A_BYTES = R_BM * R_ROWB;         // 16 KB
+constexpr int R_STAGE = (R_BM + R_BN) * R_ROWB;  // 24 KB
+constexpr int R_PS = (R_BM + R_BN) / 16 / 4;     // 6 DMA instructions per wave per K-step
+
+__device__ __forceinline__ int r_gsw(int row) { return (0 - (row >> 2)) & 3; }
+__device__ __forceinline__ int r_swz(int row, int chunk) { return row * R_ROWB + (((chunk ^ r_gsw(row)) & 3) << 4); }
+template <int OFF>
+__device__ __forceinline__ uint4 r_read128(unsigned addr) {
+  gu32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return uint4{v[0], v[1], v[2], v[3]};
+}
+template <int N>
+__device__ __forceinline__ void r_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename TC>
+__global__ void __launch_bounds__(256, 2) gemm_r3_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef bf16_t T;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int nblk = g.tiles_m * g.tiles_n;
+  int tile;
+  {  // XCD-aware tile order as in gemm_kernel
+    const int bid = blockIdx.x, xcd = bid & 7, loc = bid >> 3;
+    const int q = nblk >> 3, rm = nblk & 7;
+    tile = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + loc;
+  }
+  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  const int m0 = tm * R_BM, n0 = tn * R_BN;
+  const int nk = g.K >> 5;
+
+  // per-lane DMA source rows (clamped: products of rows past M / N are never stored)
+  const int prow = lane >> 2;
+  const int csrc = ((lane & 3) ^ r_gsw(prow)) & 3;  // logical chunk that must land at position lane & 3
+  const T* pa[4];
+  const T* pb[2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    int row = m0 + 16 * (wave + 4 * q) + prow;
+    if (row >= g.M) row = g.M - 1;
+    pa[q] = static_cast<const T*>(g.A) + (int64_t)row * g.lda + 8 * csrc;
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    int row = n0 + 16 * (wave + 4 * q) + prow;
+    if (row >= g.N) row = g.N - 1;
+    pb[q] = static_cast<const T*>(g.B) + (int64_t)row * g.ldb + 8 * csrc;
+  }
+  auto issue = [&](int s) {
+    char* st = smem + (s % R_NST) * R_STAGE + wave * 1024;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[q] + s * 32),
+                                       (__attribute__((address_space(3))) void*)(st + q * 4096), 16, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb[q] + s * 32),
+                                       (__attribute__((address_space(3))) void*)(st + R_A_BYTES + q * 4096), 16, 0, 0);
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const unsigned smem_base = (unsigned)(size_t)((const __attribute__((address_space(3))) char*)smem);
+  const unsigned a_off = (unsigned)r_swz(wm * 128 + fr, fq);
+  const unsigned b_off = (unsigned)(R_A_BYTES + r_swz(wn * 64 + fr, fq));
+
+  issue(0);
+  if (nk > 1) issue(1);
+  for (int s = 0; s < nk; ++s) {
+    // K-step s has landed (this wave's pieces); the younger operations are step s+1's pieces
+    if (s + 1 < nk) r_wait_vm<R_PS>(); else r_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();  // ... everybody's; and everybody is done reading stage (s-1) % 3
+    if (s + 2 < nk) issue(s + 2);  // -> stage (s+2) % 3 == (s-1) % 3
+    const unsigned sa = smem_base + (unsigned)((s % R_NST) * R_STAGE) + a_off;
+    const unsigned sb = smem_base + (unsigned)((s % R_NST) * R_STAGE) + b_off;
+    uint4 bf[4], af[8];
+    bf[0] = r_read128<0>(sb);
+    bf[1] = r_read128<1024>(sb);
+    bf[2] = r_read128<2048>(sb);
+    bf[3] = r_read128<3072>(sb);
+    af[0] = r_read128<0>(sa);
+    af[1] = r_read128<1024>(sa);
+    af[2] = r_read128<2048>(sa);
+    af[3] = r_read128<3072>(sa);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    af[4] = r_read128<4096>(sa);
+    af[5] = r_read128<5120>(sa);
+    af[6] = r_read128<6144>(sa);
+    af[7] = r_read128<7168>(sa);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mma_frag<T>(bf[j], af[i], acc[i][j]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 4; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mma_frag<T>(bf[j], af[i], acc[i][j]);
+  }
+  epilogue_tile<T, TC, 8, 4>(acc, g, m0 + wm * 128, n0 + wn * 64, fr, fq);
+}
+
+// ---- weight-gradient kernel: both operands K-major (dW[M,N] += A[K,M]^T . B[K,N]), bf16, split-K + fp32 atomics ----
+// PMC on the register-transposing path (1536x384x65536): MFMA busy 20 %, a third of the LDS cycles are the 2-way
+// conflicts of the transposing ds_write_b64, and with 128x128 tiles the launch pulls 1.2 GB through L2.  Here the
+// K-major tiles go to LDS untouched by LDS-DMA ([k][128 x] sub-images of 32 rows x 256 B) and the MFMA fragments
+// are gathered by the CDNA4 transposing read ds_read_b64_tr_b16 (16 lanes read a 4 x 16 block and receive it
+// column-major: lane i gets column i of 4 consecutive k) -- no VGPR round trip, no ds_write, no permutes.
+// Tile 256x128 or 128x256 (FI x FJ = 8x4 / 4x8 accumulators per wave, 2x2 waves), K-step 32, 3-stage ring of 24 KB
+// -> two workgroups per CU as gemm_r3_kernel.  Sub-image layout (cdna_hip_programming.md T10, image (b)):
+// 16-byte chunk ch of k-row r at  256 r + 16 (ch ^ (((r & 3) << 2) | ((r >> 2) & 3))); the DMA writes lane-linear
+// (4 rows per wave-instruction), so the XOR is applied to the per-lane source column.
+constexpr int T_SUB = 32 * 256;        // one sub-image: 32 k-rows x 128 elements
+constexpr int T_STAGE = 3 * T_SUB;     // A sub-images then B sub-images (2 + 1 or 1 + 2)
+constexpr int T_NST = 3;
+constexpr int T_PS = 6;                // DMA instructions per wave per K-step (24 pieces of 4 rows / 4 waves)
+
+template <int OFF>
+__device__ __forceinline__ uint2 t_read_tr(unsigned addr) {
+  typedef unsigned tu32x2 __attribute__((ext_vector_type(2)));
+  tu32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return uint2{v[0], v[1]};
+}
+
+// PART: the split-K partial goes to a dense scratch [split][M][N] with plain 16-byte stores (swapped MFMA operands:
+// a lane owns 4 consecutive columns) and splitk_reduce_kernel adds the slices to C -- global fp32 atomics move only
+// ~1.3 TB/s chip-wide, and with ~500 workgroups x 128 KB of accumulators they cost as much as the whole K loop.
+template <int FI, int FJ, bool PART>
+__global__ void __launch_bounds__(256, 2) gemm_tr_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef bf16_t T;
+  static_assert((FI == 8 && FJ == 4) || (FI == 4 && FJ == 8), "256x128 or 128x256");
+  constexpr int TBM = 32 * FI, TBN = 32 * FJ;
+  constexpr int NA = TBM / 128;  // A sub-images per stage (B: 3 - NA)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+  // Workgroup -> (output tile, K slice z).  All tiles of one K slice read the same A / B rows, so they must share an
+  // L2: workgroups b and b+8 land on the same XCD (round-robin dispatch), hence XCD x = b & 7 takes the slices
+  // z = x, x+8, ... and walks the tiles of one slice before the next.  (With the plain (tile, z) grid the tiles of
+  // a slice were spread over all 8 XCDs: PMC showed 73 % L2 misses and ~700 MB of fabric reads per launch for
+  // 250 MB of operands.)  g.wide carries the number of slices.
+  const int nblk = g.tiles_m * g.tiles_n;
+  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  const int zsl = xcd + 8 * (loc / nblk), tile = loc % nblk;
+  if (zsl >= g.wide) return;  // uniform per block
+  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  const int m0 = tm * TBM, n0 = tn * TBN;
+  const int s_begin = zsl * g.k_tiles_per_split;  // K-steps of 32 rows
+  int s_end = s_begin + g.k_tiles_per_split;
+  if (s_end > (g.K >> 5)) s_end = g.K >> 5;
+  const int ns = s_end - s_begin;
+  if (ns <= 0) return;  // uniform per block
+
+  // ---- DMA: this wave's pieces P = wave + 4q (q < 6); sub-image P >> 3, rows 4 (P & 7) .. +3 of it
+  const int drow = lane >> 4;
+  const int dsw = ((drow & 3) << 2) | (wave & 3);  // f(row) of the destination row: (P & 7) & 3 == wave & 3
+  const int dchunk = (lane & 15) ^ dsw;            // logical chunk that must land at position lane & 15
+  const T* src[T_PS];
+#pragma unroll
+  for (int q = 0; q < T_PS; ++q) {
+    const int P = wave + 4 * q, S = P >> 3, lp = P & 7;
+    const bool isA = S < NA;
+    int x = (isA ? m0 + 128 * S : n0 + 128 * (S - NA)) + 8 * dchunk;
+    const int X = isA ? g.M : g.N;
+    if (x > X - 8) x = X - 8;  // columns past the operand: clamped (their products are never accumulated)
+    const T* base = static_cast<const T*>(isA ? g.A : g.B);
+    src[q] = base + (int64_t)(s_begin * 32 + 4 * lp + drow) * (isA ? g.lda : g.ldb) + x;
+  }
+  const int64_t stepA = (int64_t)32 * g.lda, stepB = (int64_t)32 * g.ldb;
+  auto issue = [&](int s) {  // s = step index relative to s_begin
+    char* st = smem + (s % T_NST) * T_STAGE;
+#pragma unroll
+    for (int q = 0; q < T_PS; ++q) {
+      const int P = wave + 4 * q, S = P >> 3, lp = P & 7;
+      const T* p = src[q] + s * (S < NA ? stepA : stepB);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                       (__attribute__((address_space(3))) void*)(st + S * T_SUB + lp * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[FI][FJ];
+#pragma unroll
+  for (int i = 0; i < FI; ++i)
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- transposed fragment reads: lane = 16 g + 4 q + p supplies row 8 g + 4 t + q, columns 4 p .. 4 p + 3 of the
+  // fragment's 16-column block; fragment fi only flips chunk bits: address ^ (fi << 5)
+  const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+  auto tr_base = [&](int t, int xb8) {  // xb8 = (first column of the wave's share inside the sub-image) / 8
+    const int krow = 8 * tg + 4 * t + tq;
+    const int f = (tq << 2) | ((2 * tg + t) & 3);
+    return (unsigned)(256 * krow + 16 * ((xb8 + (tp >> 1)) ^ f) + 8 * (tp & 1));
+  };
+  const unsigned smem_base = (unsigned)(size_t)((const __attribute__((address_space(3))) char*)smem);
+  // A: FI == 8 -> the wave owns sub-image wm entirely; FI == 4 -> columns 64 wm .. of the single sub-image
+  const unsigned a_sub = (FI == 8) ? wm * T_SUB : 0, a_xb8 = (FI == 8) ? 0 : 8 * wm;
+  const unsigned b_sub = NA * T_SUB + ((FJ == 8) ? wn * T_SUB : 0), b_xb8 = (FJ == 8) ? 0 : 8 * wn;
+  const unsigned a_t0 = a_sub + tr_base(0, a_xb8), a_t1 = a_sub + tr_base(1, a_xb8);
+  const unsigned b_t0 = b_sub + tr_base(0, b_xb8), b_t1 = b_sub + tr_base(1, b_xb8);
+
+  issue(0);
+  if (ns > 1) issue(1);
+  for (int s = 0; s < ns; ++s) {
+    if (s + 1 < ns) r_wait_vm<T_PS>(); else r_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    if (s + 2 < ns) issue(s + 2);
+    const unsigned sb = smem_base + (unsigned)((s % T_NST) * T_STAGE);
+    uint4 af[FI], bf[FJ];
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) {
+      const uint2 lo = t_read_tr<0>(sb + (b_t0 ^ (unsigned)(j << 5)));
+      const uint2 hi = t_read_tr<0>(sb + (b_t1 ^ (unsigned)(j << 5)));
+      bf[j] = uint4{lo.x, lo.y, hi.x, hi.y};
+    }
+#pragma unroll
+    for (int i = 0; i < FI; ++i) {
+      const uint2 lo = t_read_tr<0>(sb + (a_t0 ^ (unsigned)(i << 5)));
+      const uint2 hi = t_read_tr<0>(sb + (a_t1 ^ (unsigned)(i << 5)));
+      af[i] = uint4{lo.x, lo.y, hi.x, hi.y};
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+      for (int j = 0; j < FJ; ++j) {
+        if constexpr (PART)
+          mma_frag<T>(bf[j], af[i], acc[i][j]);
+        else
+          mma_frag<T>(af[i], bf[j], acc[i][j]);
+      }
+  }
+
+  if constexpr (PART) {
+    float* P = static_cast<float*>(g.C2) + (int64_t)zsl * g.M * g.N;
+#pragma unroll
+    for (int i = 0; i < FI; ++i) {
+      const int m = m0 + wm * 16 * FI + 16 * i + fr;
+#pragma unroll
+      for (int j = 0; j < FJ; ++j) {
+        const int n = n0 + wn * 16 * FJ + 16 * j + 4 * fq;
+        if (m < g.M && n < g.N) store4(P + (int64_t)m * g.N + n, acc[i][j]);
+      }
+    }
+    return;
+  }
+  // atomic accumulate (registers walk rows, lanes walk 16 consecutive columns -> 64-byte atomic segments)
+  float* C = static_cast<float*>(g.C);
+#pragma unroll
+  for (int i = 0; i < FI; ++i)
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) {
+      const int n = n0 + wn * 16 * FJ + 16 * j + fr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 16 * FI + 16 * i + 4 * fq + r;
+        if (m < g.M && n < g.N) atomicAdd(C + (int64_t)m * g.ldc + n, acc[i][j][r]);
+      }
+    }
 }
 
 // ---- live profiler: HIP event pairs around GEMM launches on the launch stream (bench.py `roofline`) -------
@@ -426,6 +758,119 @@ int launch(const GemmArgs& g, int split, hipStream_t st) {
   return UWU_OK;
 }
 
+template <typename TC>
+int launch_r3(GemmArgs g, hipStream_t st) {
+  auto kern = gemm_r3_kernel<TC>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              R_NST * R_STAGE);
+    attr_done = true;
+  }
+  g.tiles_m = (g.M + R_BM - 1) / R_BM;
+  g.tiles_n = (g.N + R_BN - 1) / R_BN;
+  const bool rec = g_prof.on && g_prof.n < GemmProf::MAXP;
+  if (rec) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], st);
+  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(256), R_NST * R_STAGE, st, g);
+  if (rec) {
+    (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st);
+    g_prof.flops[g_prof.n] = 2.0 * g.M * g.N * g.K;
+    g_prof.kind[g_prof.n] = 0;
+    ++g_prof.n;
+  }
+  UWU_LAUNCH_CHECK("gemm_r3");
+  return UWU_OK;
+}
+// C[m][n] += sum over the split-K slices of the scratch [split][M][N]; one float4 per thread
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ C,
+                                                            int M, int N, int ldc, int split) {
+  const int64_t slice = (int64_t)M * N;
+  for (int64_t idx = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; idx < slice; idx += (int64_t)gridDim.x * 1024) {
+    f32x4 v = load4(part + idx);
+    for (int z = 1; z < split; ++z) v = v + load4(part + z * slice + idx);
+    const int m = (int)(idx / N), n = (int)(idx - (int64_t)m * N);
+    float* c = C + (int64_t)m * ldc + n;
+    store4(c, load4(c) + v);
+  }
+}
+
+// Number of K slices for the streaming weight-gradient kernel: a multiple of 8 (one group of slices per XCD), as
+// many groups as fit the XCD's 64 workgroup slots (32 CUs x 2) in one round.
+int tr_split(int tiles, int steps) {
+  int per_xcd = 64 / tiles;
+  if (per_xcd < 1) per_xcd = 1;
+  int split = 8 * per_xcd;
+  while (split > 8 && split * 4 > steps) split -= 8;  // keep >= 4 K-steps per slice
+  if (split > steps) split = steps;
+  return split < 1 ? 1 : split;
+}
+
+template <int FI, int FJ>
+int launch_tr(GemmArgs g, void* scratch, size_t scratch_bytes, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tr_kernel<FI, FJ, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, T_NST * T_STAGE);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tr_kernel<FI, FJ, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, T_NST * T_STAGE);
+    attr_done = true;
+  }
+  g.tiles_m = (g.M + 32 * FI - 1) / (32 * FI);
+  g.tiles_n = (g.N + 32 * FJ - 1) / (32 * FJ);
+  const int tiles = g.tiles_m * g.tiles_n, steps = g.K / 32;
+  int split = tr_split(tiles, steps);
+  g.k_tiles_per_split = (steps + split - 1) / split;
+  split = (steps + g.k_tiles_per_split - 1) / g.k_tiles_per_split;
+  g.wide = split;
+  const int grid = 8 * tiles * ((split + 7) / 8);
+  // scratch path needs 16-byte rows in the scratch and in C
+  const bool part = scratch && split > 1 && g.N % 4 == 0 && g.ldc % 4 == 0 && (((uintptr_t)g.C | (uintptr_t)scratch) & 15) == 0 &&
+                    scratch_bytes >= (size_t)split * g.M * g.N * sizeof(float);
+  const bool rec = g_prof.on && g_prof.n < GemmProf::MAXP;
+  if (rec) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], st);
+  if (part) {
+    g.C2 = scratch;
+    hipLaunchKernelGGL((gemm_tr_kernel<FI, FJ, true>), dim3(grid), dim3(256), T_NST * T_STAGE, st, g);
+    const int64_t quads = (int64_t)g.M * g.N / 4;
+    int rg = (int)((quads + 255) / 256);
+    if (rg > 4096) rg = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, st, static_cast<const float*>(scratch),
+                       static_cast<float*>(g.C), g.M, g.N, g.ldc, split);
+  } else {
+    hipLaunchKernelGGL((gemm_tr_kernel<FI, FJ, false>), dim3(grid), dim3(256), T_NST * T_STAGE, st, g);
+  }
+  if (rec) {
+    (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st);
+    g_prof.flops[g_prof.n] = 2.0 * g.M * g.N * g.K;
+    g_prof.kind[g_prof.n] = 0;
+    ++g_prof.n;
+  }
+  UWU_LAUNCH_CHECK("gemm_tr");
+  return UWU_OK;
+}
+// K-major x K-major accumulate (the weight gradients): 0 = keep the 128x128 kernel, 1 = 256x128, 2 = 128x256
+int pick_tr(const GemmArgs& g) {
+  const char* e = getenv("UWU_GEMM_TR");  // "0": off (A/B comparisons)
+  if (e && e[0] == '0') return 0;
+  if (g.K % 32 || g.K < 96 || g.M % 8 || g.N % 8 || g.M < 8 || g.N < 8) return 0;
+  if ((((uintptr_t)g.A | (uintptr_t)g.B) & 15) || g.lda % 8 || g.ldb % 8) return 0;
+  auto padded = [](int x, int b) { return (double)(((x + b - 1) / b) * b) / x; };
+  const double w1 = padded(g.M, 256) * padded(g.N, 128), w2 = padded(g.M, 128) * padded(g.N, 256);
+  const double w0 = padded(g.M, 128) * padded(g.N, 128);
+  if ((w1 < w2 ? w1 : w2) > 1.35 * w0) return 0;  // too much padding: the small tile wastes less
+  if (g.K < 2048) return 0;                       // short reductions: nothing to stream
+  return w1 <= w2 ? 1 : 2;
+}
+
+// the 256x128 kernel pays off on the wide-N Linears (65536x1152x384: 92 us against 104; x1536: 128 against 147); with
+// 768 tiles (N = 384) the second round of 512 workgroup slots is half empty and the 128x128 kernel stays ahead
+bool use_r3(const GemmArgs& g) {
+  const char* e = getenv("UWU_GEMM_R3");  // "0": off (A/B comparisons)
+  if (e && e[0] == '0') return false;
+  const int64_t tiles = (int64_t)((g.M + R_BM - 1) / R_BM) * ((g.N + R_BN - 1) / R_BN);
+  return g.K % 32 == 0 && g.K >= 96 && tiles >= 1024;
+}
+
 bool no_glds() {
   static int v = -1;
   if (v < 0) {
@@ -439,6 +884,13 @@ template <typename T, typename TC>
 int dispatch_trans(const GemmArgs& g, int ta, int tb, bool acc, int split, hipStream_t st) {
   if (acc) {
     if constexpr (sizeof(TC) == 4) {
+      if constexpr (sizeof(T) == 2) {
+        if (ta == 1 && tb == 1) {
+          const int tr = split > 1 ? pick_tr(g) : 0;  // the streaming kernel chooses its own number of K slices
+          if (tr == 1) return launch_tr<8, 4>(g, nullptr, 0, st);
+          if (tr == 2) return launch_tr<4, 8>(g, nullptr, 0, st);
+        }
+      }
       if (ta == 1 && tb == 1) return launch<T, float, true, true, true>(g, split, st);
       if (ta == 0 && tb == 0) return launch<T, float, false, false, true>(g, split, st);
       if (ta == 0 && tb == 1) return launch<T, float, false, true, true>(g, split, st);
@@ -447,6 +899,9 @@ int dispatch_trans(const GemmArgs& g, int ta, int tb, bool acc, int split, hipSt
     return UWU_EINVAL;
   }
   if (ta == 0 && tb == 0) {
+    if constexpr (sizeof(T) == 2) {
+      if (use_r3(g)) return launch_r3<TC>(g, st);
+    }
     if (g.K % GT<T>::BK == 0 && !no_glds()) return launch<T, TC, false, false, false, true>(g, split, st);
     return launch<T, TC, false, false, false>(g, split, st);
   }
@@ -547,6 +1002,39 @@ extern "C" int uwu_gemm(const void* A, const void* B, void* C, void* C2, const f
     return dispatch_trans<bf16_t, float>(g, transA, transB, acc, split, st);
   }
   return dispatch_trans<float, float>(g, transA, transB, acc, split, st);
+}
+
+// Weight gradient with caller-provided split-K scratch: C[M,N] (fp32) += A[K,M]^T . B[K,N], operands K-major.
+// When `scratch` holds uwu_gemm_wgrad_scratch_bytes(M, N, K) the split-K slices of the streaming kernel are written
+// there and reduced by a second kernel; otherwise its slices are accumulated with atomics.  Shapes the streaming
+// kernel does not take go to uwu_gemm(..., UWU_EPI_ACCUM) with `blocks` workgroups as the split-K target.
+extern "C" size_t uwu_gemm_wgrad_scratch_bytes(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K < 32) return 0;
+  // the larger of the two tile orientations' slice counts (pick_tr chooses by padding)
+  const int t1 = ((M + 255) / 256) * ((N + 127) / 128), t2 = ((M + 127) / 128) * ((N + 255) / 256);
+  const int s1 = tr_split(t1, K / 32), s2 = tr_split(t2, K / 32);
+  return (size_t)(s1 > s2 ? s1 : s2) * M * N * sizeof(float);
+}
+
+extern "C" int uwu_gemm_wgrad(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                              int dtype, int blocks, void* scratch, size_t scratch_bytes, void* stream) {
+  UWU_CHECK_ARG(A && B && C, "gemm_wgrad: null operand");
+  UWU_CHECK_ARG(M > 0 && N > 0 && K > 0 && blocks > 0, "gemm_wgrad: bad shape M=%d N=%d K=%d blocks=%d", M, N, K, blocks);
+  UWU_CHECK_ARG(dtype == UWU_F32 || dtype == UWU_BF16, "gemm_wgrad: bad dtype %d", dtype);
+  UWU_CHECK_ARG(lda >= M && ldb >= N && ldc >= N, "gemm_wgrad: leading dimension too small");
+  if (dtype == UWU_BF16) {
+    GemmArgs g{};
+    g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.epi = UWU_EPI_ACCUM;
+    const int tr = pick_tr(g);
+    if (tr == 1) return launch_tr<8, 4>(g, scratch, scratch_bytes, (hipStream_t)stream);
+    if (tr == 2) return launch_tr<4, 8>(g, scratch, scratch_bytes, (hipStream_t)stream);
+  }
+  const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  const int bk = dtype == UWU_BF16 ? 64 : 32;
+  int split = (blocks + tiles - 1) / tiles;
+  if (split > (K + bk - 1) / bk) split = (K + bk - 1) / bk;
+  return uwu_gemm(A, B, C, nullptr, nullptr, nullptr, M, N, K, lda, ldb, ldc, 0, 1, 1, dtype, UWU_F32, UWU_EPI_ACCUM,
+                  split, stream);
 }
 
 // Enable/disable recording of a HIP event pair around every uwu_gemm launch (on that launch's stream).

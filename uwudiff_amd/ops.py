@@ -172,3 +172,18 @@ def cl_to_nchw(x, B, C, HW):
     out = torch.empty(B, C, HW, device=x.device, dtype=torch.float32)
     L.call("uwu_cl_to_nchw", L.ptr(x), L.ptr(out), B, C, HW, L.dt(x), L.stream())
     return out
+
+
+def gemm_wgrad(dy, x, dw, blocks=512, scratch=None):
+    """dw[M,N] (fp32) += dy[K,M]^T @ x[K,N] -- weight gradient of a Linear; ``scratch`` (a byte tensor from
+    :func:`gemm_wgrad_scratch`) switches the split-K reduction from fp32 atomics to slices + a reduce kernel."""
+    K, M = dy.shape
+    K2, N = x.shape
+    assert K == K2 and dw.shape == (M, N) and dw.dtype == torch.float32 and dy.dtype == x.dtype
+    L.call("uwu_gemm_wgrad", L.ptr(dy), L.ptr(x), L.ptr(dw), M, N, K, dy.stride(0), x.stride(0), dw.stride(0), L.dt(dy),
+           blocks, L.ptr(scratch), scratch.numel() if scratch is not None else 0, L.stream())
+    return dw
+
+
+def gemm_wgrad_scratch(M, N, K, device="cuda"):
+    return torch.empty(L.load().uwu_gemm_wgrad_scratch_bytes(M, N, K), dtype=torch.uint8, device=device)
