@@ -137,10 +137,12 @@ int uwu_gemm(const void* A, const void* B, void* C, void* C2, const float* bias,
  * uwu_gemm_wgrad_scratch_bytes(M, N, K) bytes the slices are written there and summed by a second kernel, with
  * scratch == NULL they are accumulated with fp32 atomics.  Other shapes / fp32 operands are
  * uwu_gemm(transA=1, transB=1, UWU_EPI_ACCUM) with `blocks` workgroups as the split-K target.
+ * bias_grad (optional, fp32[M]) += column sums of A = the Linear's bias gradient; the streaming kernel computes it
+ * with extra MFMAs against an all-ones fragment instead of a separate pass over dY.
  * Results differ only in summation order. */
 size_t uwu_gemm_wgrad_scratch_bytes(int M, int N, int K);
-int uwu_gemm_wgrad(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int dtype,
-                   int blocks, void* scratch, size_t scratch_bytes, void* stream);
+int uwu_gemm_wgrad(const void* A, const void* B, float* C, float* bias_grad, int M, int N, int K, int lda, int ldb,
+                   int ldc, int dtype, int blocks, void* scratch, size_t scratch_bytes, void* stream);
 
 /* Live measurement for bench.py's `roofline` object: when enabled, every uwu_gemm launch is bracketed by a HIP
  * event pair recorded on that launch's stream; collect() returns the summed launch duration, the summed

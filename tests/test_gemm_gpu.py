@@ -220,11 +220,16 @@ def test_gemm_wgrad_scratch_path(M, N, K):
 
     a, b = _operands(M, N, K, True, True, torch.bfloat16, ints=True, seed=13)
     want = a.float().t() @ b.float() + 2.0
+    bsum = a.float().sum(0) + 3.0  # the fused bias gradient: column sums of A on top of existing content
     for scratch in (ops.gemm_wgrad_scratch(M, N, K), None):
         dw = torch.full((M, N), 2.0, device="cuda")
-        ops.gemm_wgrad(a, b, dw, scratch=scratch)
+        db = torch.full((M,), 3.0, device="cuda")
+        ops.gemm_wgrad(a, b, dw, scratch=scratch, bias_grad=db)
         assert torch.equal(dw, want)
-    # fp32 operands take the 128x128 kernel with atomics
+        assert torch.equal(db, bsum)
+    # fp32 operands take the 128x128 kernel with atomics (+ the colsum kernel for the bias gradient)
     dw = torch.zeros(M, N, device="cuda")
-    ops.gemm_wgrad(a.float(), b.float(), dw)
+    db = torch.full((M,), 3.0, device="cuda")
+    ops.gemm_wgrad(a.float(), b.float(), dw, bias_grad=db)
     assert torch.equal(dw, want - 2.0)
+    assert torch.equal(db, bsum)

@@ -162,11 +162,16 @@ int lin_dgrad_splitk(const void* dY, const void* W, float* dX, int M, int N, int
                   st);
 }
 // dW[N,K] += dY[M,N]^T . X[M,K]   (fp32 atomics, split over the token dimension)
+// dW[N(out), K(in)] += dY[M, N]^T . X[M, K] and, with db, db[N] += column sums of dY (the bias gradient)
 int lin_wgrad(const void* dY, const void* X, float* dW, int M, int N, int K, int dt, void* st, void* scratch = nullptr,
-              size_t scratch_bytes = 0) {
-  // dW[N(out), K(in)] += dY[M, N]^T . X[M, K]; bf16 goes to the streaming kernel with split-K scratch when it fits
+              size_t scratch_bytes = 0, float* db = nullptr) {
+  // bf16 goes to the streaming kernel (split-K scratch, bias gradient fused as an extra all-ones column)
   if (dt == UWU_BF16 && scratch && uwu_gemm_wgrad_scratch_bytes(N, K, M) <= scratch_bytes)
-    return uwu_gemm_wgrad(dY, X, dW, N, K, M, N, K, K, dt, WGRAD_BLOCKS, scratch, scratch_bytes, st);
+    return uwu_gemm_wgrad(dY, X, dW, db, N, K, M, N, K, K, dt, WGRAD_BLOCKS, scratch, scratch_bytes, st);
+  if (db) {
+    const int rc = uwu_colsum(dY, dt, M, N, N, db, 1, st);
+    if (rc != UWU_OK) return rc;
+  }
   const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
   const int bk = dt == UWU_BF16 ? 64 : 32;
   const int ktiles = (M + bk - 1) / bk;
@@ -357,8 +362,7 @@ extern "C" int uwu_dit_backward(const uwu_dit_desc* dp, const float* dout, void*
     const float* m = mod + (int64_t)l * 6 * D;
     float* dm = dmod + (int64_t)l * 6 * D;
     // ---- MLP branch: y2 = fc2(gelu(fc1(h2)))
-    RUN(lin_wgrad(P.at(L.dy), P.lay(l, L.o_f), g + w.off_fc2_w, M, D, D4, dt, st, P.at(L.wsc), L.wsc_bytes));
-    RUN(uwu_colsum(P.at(L.dy), dt, M, D, D, g + w.off_fc2_b, 1, st));
+    RUN(lin_wgrad(P.at(L.dy), P.lay(l, L.o_f), g + w.off_fc2_w, M, D, D4, dt, st, P.at(L.wsc), L.wsc_bytes, g + w.off_fc2_b));
     // du = (dy.W2) * gelu'(u); the epilogue also accumulates colsum(du) = fc1.bias gradient
     RUN(lin_dgrad(P.at(L.dy), w.fc2_w, P.at(L.du), P.lay(l, L.o_u), M, D, D4, dt, st, g + w.off_fc1_b));
     RUN(lin_wgrad(P.at(L.du), P.lay(l, L.o_h2), g + w.off_fc1_w, M, D4, D, dt, st, P.at(L.wsc), L.wsc_bytes));
@@ -368,16 +372,14 @@ extern "C" int uwu_dit_backward(const uwu_dit_desc* dp, const float* dout, void*
                                 P.at(L.dx), P.lay(l, L.o_y1), m + 2 * D, ML, P.at(L.dx), P.at(L.dy), dm + 3 * D,
                                 dm + 4 * D, dm + 2 * D, B, T, D, 0, dt, st));
     // ---- attention branch: y1 = proj(attn(qkv(h1)))
-    RUN(lin_wgrad(P.at(L.dy), P.lay(l, L.o_ao), g + w.off_o_w, M, D, D, dt, st, P.at(L.wsc), L.wsc_bytes));
-    RUN(uwu_colsum(P.at(L.dy), dt, M, D, D, g + w.off_o_b, 1, st));
+    RUN(lin_wgrad(P.at(L.dy), P.lay(l, L.o_ao), g + w.off_o_w, M, D, D, dt, st, P.at(L.wsc), L.wsc_bytes, g + w.off_o_b));
     RUN(lin_dgrad(P.at(L.dy), w.o_w, P.at(L.dao), nullptr, M, D, D, dt, st));
     char* qkv = P.lay<char>(l, L.o_qkv);
     char* dqkv = P.at<char>(L.dqkv);
     RUN(uwu_attention_bwd(qkv, qkv + (size_t)D * es, qkv + (size_t)2 * D * es, P.lay(l, L.o_ao), P.at(L.dao),
                           P.lay<float>(l, L.o_lse), P.at<float>(L.delta), dqkv, dqkv + (size_t)D * es,
                           dqkv + (size_t)2 * D * es, B, T, T, d.H, D / d.H, D3, D3, D3, D, scale, dt, st));
-    RUN(lin_wgrad(dqkv, P.lay(l, L.o_h1), g + w.off_qkv_w, M, D3, D, dt, st, P.at(L.wsc), L.wsc_bytes));
-    RUN(uwu_colsum(dqkv, dt, M, D3, D3, g + w.off_qkv_b, 1, st));
+    RUN(lin_wgrad(dqkv, P.lay(l, L.o_h1), g + w.off_qkv_w, M, D3, D, dt, st, P.at(L.wsc), L.wsc_bytes, g + w.off_qkv_b));
     RUN(lin_dgrad(dqkv, w.qkv_w, P.at(L.dh), nullptr, M, D3, D, dt, st));
     // LN1 bwd (+ residual) and gate bwd of the previous layer's MLP branch
     if (l > 0) {

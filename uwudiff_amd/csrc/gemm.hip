@@ -647,6 +647,24 @@ __global__ void __launch_bounds__(256, 2) gemm_tr_kernel(const GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // Fused bias gradient: g.bias != NULL asks for bias[m] += sum_k A[k][m] (the column sums of dY).  That is one more
+  // output column with B = 1: extra MFMAs against a constant all-ones fragment (the MFMA pipe is 20 % busy in this
+  // kernel), and the separate colsum pass over dY (28 us per Linear) disappears.
+  // The FI row-fragments are dealt round-robin to the 2 x tiles_n waves that share this tile row, so no wave adds
+  // more than ceil(FI / (2 tiles_n)) MFMAs per K-step.
+  unsigned smask = 0;  // wave-uniform: bit i = this wave sums row-fragment i
+  if (g.bias != nullptr) {
+    const int slot = tn * 2 + wn, nslots = g.tiles_n * 2;
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+      if (i % nslots == slot) smask |= 1u << i;
+  }
+  const bool do_sum = smask != 0;
+  f32x4 sacc[FI];
+#pragma unroll
+  for (int i = 0; i < FI; ++i) sacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const uint4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};  // 8 x bf16(1.0)
+
   // ---- transposed fragment reads: lane = 16 g + 4 q + p supplies row 8 g + 4 t + q, columns 4 p .. 4 p + 3 of the
   // fragment's 16-column block; fragment fi only flips chunk bits: address ^ (fi << 5)
   const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
@@ -693,6 +711,33 @@ __global__ void __launch_bounds__(256, 2) gemm_tr_kernel(const GemmArgs g) {
         else
           mma_frag<T>(af[i], bf[j], acc[i][j]);
       }
+    if (do_sum) {
+#pragma unroll
+      for (int i = 0; i < FI; ++i) {
+        if (!((smask >> i) & 1)) continue;
+        if constexpr (PART)
+          mma_frag<T>(ones, af[i], sacc[i]);
+        else
+          mma_frag<T>(af[i], ones, sacc[i]);
+      }
+    }
+  }
+  if (do_sum) {
+    float* bg = const_cast<float*>(g.bias);
+#pragma unroll
+    for (int i = 0; i < FI; ++i) {
+      if (!((smask >> i) & 1)) continue;
+      if constexpr (PART) {  // D[n][m]: column m = fr on the lane, every row equal
+        const int m = m0 + wm * 16 * FI + 16 * i + fr;
+        if (fq == 0 && m < g.M) atomicAdd(bg + m, sacc[i][0]);
+      } else {  // D[m][n]: rows 4 fq + r in the registers, every column equal
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + wm * 16 * FI + 16 * i + 4 * fq + r;
+          if (fr == 0 && m < g.M) atomicAdd(bg + m, sacc[i][r]);
+        }
+      }
+    }
   }
 
   if constexpr (PART) {
@@ -887,8 +932,10 @@ int dispatch_trans(const GemmArgs& g, int ta, int tb, bool acc, int split, hipSt
       if constexpr (sizeof(T) == 2) {
         if (ta == 1 && tb == 1) {
           const int tr = split > 1 ? pick_tr(g) : 0;  // the streaming kernel chooses its own number of K slices
-          if (tr == 1) return launch_tr<8, 4>(g, nullptr, 0, st);
-          if (tr == 2) return launch_tr<4, 8>(g, nullptr, 0, st);
+          GemmArgs gt = g;
+          gt.bias = nullptr;  // (the fused bias gradient is uwu_gemm_wgrad's)
+          if (tr == 1) return launch_tr<8, 4>(gt, nullptr, 0, st);
+          if (tr == 2) return launch_tr<4, 8>(gt, nullptr, 0, st);
         }
       }
       if (ta == 1 && tb == 1) return launch<T, float, true, true, true>(g, split, st);
@@ -1016,8 +1063,9 @@ extern "C" size_t uwu_gemm_wgrad_scratch_bytes(int M, int N, int K) {
   return (size_t)(s1 > s2 ? s1 : s2) * M * N * sizeof(float);
 }
 
-extern "C" int uwu_gemm_wgrad(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
-                              int dtype, int blocks, void* scratch, size_t scratch_bytes, void* stream) {
+extern "C" int uwu_gemm_wgrad(const void* A, const void* B, float* C, float* bias_grad, int M, int N, int K, int lda,
+                              int ldb, int ldc, int dtype, int blocks, void* scratch, size_t scratch_bytes,
+                              void* stream) {
   UWU_CHECK_ARG(A && B && C, "gemm_wgrad: null operand");
   UWU_CHECK_ARG(M > 0 && N > 0 && K > 0 && blocks > 0, "gemm_wgrad: bad shape M=%d N=%d K=%d blocks=%d", M, N, K, blocks);
   UWU_CHECK_ARG(dtype == UWU_F32 || dtype == UWU_BF16, "gemm_wgrad: bad dtype %d", dtype);
@@ -1025,9 +1073,14 @@ extern "C" int uwu_gemm_wgrad(const void* A, const void* B, float* C, int M, int
   if (dtype == UWU_BF16) {
     GemmArgs g{};
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.epi = UWU_EPI_ACCUM;
+    g.bias = bias_grad;
     const int tr = pick_tr(g);
     if (tr == 1) return launch_tr<8, 4>(g, scratch, scratch_bytes, (hipStream_t)stream);
     if (tr == 2) return launch_tr<4, 8>(g, scratch, scratch_bytes, (hipStream_t)stream);
+  }
+  if (bias_grad) {
+    const int rc = uwu_colsum(A, dtype, K, M, lda, bias_grad, 1, stream);
+    if (rc != UWU_OK) return rc;
   }
   const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
   const int bk = dtype == UWU_BF16 ? 64 : 32;

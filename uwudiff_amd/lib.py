@@ -52,7 +52,7 @@ _SIGS = {
     "uwu_cast_bf16_to_f32": (c_int, [P, P, c_int64, P]),
     "uwu_gemm": (c_int, [P, P, P, P, P, P] + [c_int] * 13 + [P]),
     "uwu_gemm_wgrad_scratch_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
-    "uwu_gemm_wgrad": (c_int, [P, P, P] + [c_int] * 8 + [P, ctypes.c_size_t, P]),
+    "uwu_gemm_wgrad": (c_int, [P, P, P, P] + [c_int] * 8 + [P, ctypes.c_size_t, P]),
     "uwu_gemm_prof_enable": (c_int, [c_int]),
     "uwu_gemm_prof_collect": (c_int, [c_int, P, P, P]),
     "uwu_colsum": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, P]),

@@ -174,13 +174,14 @@ def cl_to_nchw(x, B, C, HW):
     return out
 
 
-def gemm_wgrad(dy, x, dw, blocks=512, scratch=None):
+def gemm_wgrad(dy, x, dw, blocks=512, scratch=None, bias_grad=None):
     """dw[M,N] (fp32) += dy[K,M]^T @ x[K,N] -- weight gradient of a Linear; ``scratch`` (a byte tensor from
-    :func:`gemm_wgrad_scratch`) switches the split-K reduction from fp32 atomics to slices + a reduce kernel."""
+    :func:`gemm_wgrad_scratch`) switches the split-K reduction from fp32 atomics to slices + a reduce kernel;
+    ``bias_grad`` (fp32[M]) += column sums of dy."""
     K, M = dy.shape
     K2, N = x.shape
     assert K == K2 and dw.shape == (M, N) and dw.dtype == torch.float32 and dy.dtype == x.dtype
-    L.call("uwu_gemm_wgrad", L.ptr(dy), L.ptr(x), L.ptr(dw), M, N, K, dy.stride(0), x.stride(0), dw.stride(0), L.dt(dy),
+    L.call("uwu_gemm_wgrad", L.ptr(dy), L.ptr(x), L.ptr(dw), L.ptr(bias_grad), M, N, K, dy.stride(0), x.stride(0), dw.stride(0), L.dt(dy),
            blocks, L.ptr(scratch), scratch.numel() if scratch is not None else 0, L.stream())
     return dw
 
