@@ -66,6 +66,14 @@ def main():
             else:
                 out = torch.empty(m, n, device=dev, dtype=bf)
                 fn = lambda: ops.gemm(a, b, trans_a=False, trans_b=bool(tb), out=out)
+                if name == "fc1_fwd":  # the in-step call: bias + GELU, two outputs
+                    bias, out2 = torch.randn(n, device=dev), torch.empty(m, n, device=dev, dtype=bf)
+                    us = timeit(lambda: ops.gemm(a, b, bias=bias, epilogue=L.EPI_BIAS_GELU, out=out, out2=out2))
+                    print(f"{name + '+gelu':10s} {us:9.1f} us  {fl / us / 1e6:8.1f} TFLOP/s   ({m}x{n}x{k})")
+                if name == "fc2_dgrad":  # the in-step call: x gelu'(u) and the fc1 bias gradient
+                    u, cs = torch.randn(m, n, device=dev).to(bf), torch.zeros(n, device=dev)
+                    us = timeit(lambda: ops.gemm(a, b, trans_b=True, aux=u, epilogue=L.EPI_DGELU, out=out, out2=cs))
+                    print(f"{name + '+dg':10s} {us:9.1f} us  {fl / us / 1e6:8.1f} TFLOP/s   ({m}x{n}x{k})")
             us = timeit(fn)
             print(f"{name:10s} {us:9.1f} us  {fl / us / 1e6:8.1f} TFLOP/s   ({m}x{n}x{k})")
     if want("ln"):

@@ -127,6 +127,29 @@ __device__ __forceinline__ float dgelu_tanh_f(float x) {
   const float s = gelu_sig_f(x, x2);
   return s + x * s * (1.f - s) * (D0 + D1 * x2);
 }
+// Two elements at a time: the multiplies / adds / fmas become v_pk_*_f32 (two fp32 per lane per instruction; only
+// v_exp_f32 / v_rcp_f32 stay scalar).  The GEMM epilogues that apply these are VALU-bound.
+__device__ __forceinline__ f32x2 gelu_sig_f2(f32x2 x, f32x2 x2) {
+  const float CA = -2.f * 1.4426950408889634f * 0.7978845608028654f, CB = CA * 0.044715f;
+  const f32x2 z = x * (f32x2{CA, CA} + f32x2{CB, CB} * x2);
+  const f32x2 d = f32x2{1.f, 1.f} + f32x2{__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])};
+  return f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+}
+__device__ __forceinline__ f32x2 gelu_tanh_f2(f32x2 x) { return x * gelu_sig_f2(x, x * x); }
+__device__ __forceinline__ f32x2 dgelu_tanh_f2(f32x2 x) {
+  const float D0 = 2.f * 0.7978845608028654f, D1 = 3.f * 0.044715f * D0;
+  const f32x2 x2 = x * x;
+  const f32x2 s = gelu_sig_f2(x, x2);
+  return s + (x * s) * ((f32x2{1.f, 1.f} - s) * (f32x2{D0, D0} + f32x2{D1, D1} * x2));
+}
+__device__ __forceinline__ f32x4 gelu_tanh_f4(f32x4 x) {
+  const f32x2 a = gelu_tanh_f2(f32x2{x[0], x[1]}), b = gelu_tanh_f2(f32x2{x[2], x[3]});
+  return f32x4{a[0], a[1], b[0], b[1]};
+}
+__device__ __forceinline__ f32x4 dgelu_tanh_f4(f32x4 x) {
+  const f32x2 a = dgelu_tanh_f2(f32x2{x[0], x[1]}), b = dgelu_tanh_f2(f32x2{x[2], x[3]});
+  return f32x4{a[0], a[1], b[0], b[1]};
+}
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 // elementwise launch: cap at 256 CUs x 8 blocks and grid-stride the rest

@@ -20,6 +20,8 @@
 // operands are transposed in registers (4x8 bf16 / 4x4 fp32 blocks) so HBM reads stay 16 B/lane coalesced.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -178,34 +180,87 @@ struct GemmArgs {
 // Epilogue of one wave tile of FI x FJ 16x16 accumulators in the swapped-operand orientation (each lane owns 4
 // consecutive columns of one row): bias / GELU / dGELU(+column sums) math and 8- or 16-byte stores.
 // (m_w, n_w) = first row / column of the wave tile.
-template <typename T, typename TC, int FI, int FJ>
-__device__ __forceinline__ void epilogue_tile(f32x4 (&acc)[FI][FJ], const GemmArgs& g, int m_w, int n_w, int fr,
-                                              int fq) {
+// EPI >= 0 fixes the epilogue at compile time (the hot bf16 instantiations: a third of the code and no branches in
+// the 16..32-fold unrolled store loops); EPI = -1 reads g.epi at run time.
+// What the epilogue READS (bias, dGELU's aux), fetched by epi_prefetch() at KERNEL START: C / C2 / aux / bias carry
+// no restrict, so the compiler keeps a load that follows a store in program order behind it, and loads placed inside
+// the per-fragment loop exposed one full memory latency per fragment; loaded at the top of the epilogue they still
+// cost one exposed HBM latency per tile while the workgroup holds its LDS and registers.  Issued before the K loop
+// they are simply there.  Bias: one float4 per column fragment.  aux: a ring of PD rows of fragments (row i + PD is
+// loaded when row i has been consumed).
+template <typename T, int FI, int FJ>
+struct EpiPre {
+  static constexpr int PD = FI < 4 ? FI : 4;
+  typedef typename std::conditional<sizeof(T) == 2, uint2, f32x4>::type AuxRaw;
+  f32x4 bias[FJ];
+  AuxRaw aux[PD][FJ];
+};
+template <typename T, int FI, int FJ>
+__device__ __forceinline__ void epi_load_aux_row(const GemmArgs& g, int m_w, int n_w, int fr, int fq, int i,
+                                                 typename EpiPre<T, FI, FJ>::AuxRaw (&dst)[FJ]) {
+  typedef typename EpiPre<T, FI, FJ>::AuxRaw AuxRaw;
+  const T* aux = static_cast<const T*>(g.aux);
+  const int m = m_w + 16 * i + fr;
+#pragma unroll
+  for (int j = 0; j < FJ; ++j) {
+    const int n = n_w + 16 * j + 4 * fq;
+    if (m < g.M && n < g.N) dst[j] = *reinterpret_cast<const AuxRaw*>(aux + (int64_t)m * g.ldaux + n);
+    else dst[j] = AuxRaw{};
+  }
+}
+template <typename T, int FI, int FJ, int EPI>
+__device__ __forceinline__ void epi_prefetch(EpiPre<T, FI, FJ>& pre, const GemmArgs& g, int m_w, int n_w, int fr,
+                                             int fq) {
+  const int epi = EPI >= 0 ? EPI : g.epi;
+  const bool has_bias = epi == UWU_EPI_BIAS || epi == UWU_EPI_BIAS_GELU || epi == UWU_EPI_BIAS_SILU;
+#pragma unroll
+  for (int j = 0; j < FJ; ++j) {
+    const int n = n_w + 16 * j + 4 * fq;
+    pre.bias[j] = (has_bias && n < g.N) ? load4(g.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if (epi == UWU_EPI_DGELU) {
+#pragma unroll
+    for (int i = 0; i < EpiPre<T, FI, FJ>::PD; ++i) epi_load_aux_row<T, FI, FJ>(g, m_w, n_w, fr, fq, i, pre.aux[i]);
+  }
+}
+
+template <typename T, typename TC, int FI, int FJ, int EPI = -1>
+__device__ __forceinline__ void epilogue_tile(f32x4 (&acc)[FI][FJ], EpiPre<T, FI, FJ>& pre, const GemmArgs& g, int m_w,
+                                              int n_w, int fr, int fq) {
   TC* C = static_cast<TC*>(g.C);
   TC* C2 = static_cast<TC*>(g.C2);
-  const T* aux = static_cast<const T*>(g.aux);
-  const int epi = g.epi;
-  // per-subtile epilogue math on this lane's 4 consecutive columns
-  auto finish = [&](f32x4 v, int m, int n, f32x4& second) {
-    if (epi == UWU_EPI_BIAS || epi == UWU_EPI_BIAS_GELU || epi == UWU_EPI_BIAS_SILU) v = v + load4(g.bias + n);
-    if (epi == UWU_EPI_DGELU) {
-      f32x4 u = load4(aux + (int64_t)m * g.ldaux + n);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] *= dgelu_tanh_f(u[e]);
+  const int epi = EPI >= 0 ? EPI : g.epi;
+  const bool has_bias = epi == UWU_EPI_BIAS || epi == UWU_EPI_BIAS_GELU || epi == UWU_EPI_BIAS_SILU;
+  const bool two = epi == UWU_EPI_BIAS_GELU || epi == UWU_EPI_BIAS_SILU;
+  const bool dgelu = epi == UWU_EPI_DGELU;
+  constexpr int PD = EpiPre<T, FI, FJ>::PD;
+  typedef typename EpiPre<T, FI, FJ>::AuxRaw AuxRaw;
+  auto aux_f32 = [](const AuxRaw& r) {
+    if constexpr (sizeof(T) == 2) {
+      const bf16x4 b = *reinterpret_cast<const bf16x4*>(&r);
+      return f32x4{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+    } else {
+      return r;
+    }
+  };
+
+  // per-fragment math on this lane's 4 consecutive columns
+  auto finish = [&](f32x4 v, const f32x4& b, const AuxRaw& a, f32x4& second) {
+    if (has_bias) v = v + b;
+    if (dgelu) {
+      v = v * dgelu_tanh_f4(aux_f32(a));
     }
     if (epi == UWU_EPI_BIAS_GELU) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) second[e] = gelu_tanh_f(v[e]);
+      second = gelu_tanh_f4(v);
     } else if (epi == UWU_EPI_BIAS_SILU) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) second[e] = silu_f(v[e]);
     }
     return v;
   };
-  const bool two = epi == UWU_EPI_BIAS_GELU || epi == UWU_EPI_BIAS_SILU;
   // UWU_EPI_DGELU with C2 != NULL: C2 is a float[N] that receives += the column sums of C (the bias gradient of
   // the Linear whose pre-activation is `aux`), summed over this tile's rows in registers / lanes, then atomics
-  float* colsum = (epi == UWU_EPI_DGELU) ? reinterpret_cast<float*>(g.C2) : nullptr;
+  float* colsum = dgelu ? reinterpret_cast<float*>(g.C2) : nullptr;
   f32x4 csum[FJ];
 #pragma unroll
   for (int j = 0; j < FJ; ++j) csum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -233,33 +288,36 @@ __device__ __forceinline__ void epilogue_tile(f32x4 (&acc)[FI][FJ], const GemmAr
       }
     }
   };
-  if constexpr (sizeof(TC) == 2) {
-    // bf16 output: stores are instruction-bound (fp32 output of the same tile costs the same per store), so
-    // pair lanes l and l^16 (column groups fq, fq^1) and swap half of two neighbouring 16-column subtiles:
-    // even fq keeps subtile 2jp (own 4 columns + partner's next 4), odd fq keeps subtile 2jp+1 -> one 16-B store
-    // per lane covering 8 consecutive columns, 64 contiguous bytes per row per instruction, half the stores.
-    if (g.wide) {
-      const bool odd = fq & 1;
+  // bf16 output: stores are instruction-bound (fp32 output of the same tile costs the same per store), so
+  // pair lanes l and l^16 (column groups fq, fq^1) and swap half of two neighbouring 16-column subtiles:
+  // even fq keeps subtile 2jp (own 4 columns + partner's next 4), odd fq keeps subtile 2jp+1 -> one 16-B store
+  // per lane covering 8 consecutive columns, 64 contiguous bytes per row per instruction, half the stores.
+  const bool wide = sizeof(TC) == 2 && g.wide;
+  const bool odd = fq & 1;
+  auto pack = [](const f32x4& v) {
+    bf16x4 b = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    return *reinterpret_cast<uint2*>(&b);
+  };
 #pragma unroll
-      for (int i = 0; i < FI; ++i) {
-        const int m = m_w + 16 * i + fr;
-        const bool mok = m < g.M;
+  for (int i = 0; i < FI; ++i) {
+    const int m = m_w + 16 * i + fr;
+    const bool mok = m < g.M;
+    AuxRaw(&arow)[FJ] = pre.aux[i % PD];
+    f32x4 v[FJ], sec[FJ];
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) {
+      const int n = n_w + 16 * j + 4 * fq;
+      sec[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      v[j] = (mok && n < g.N) ? finish(acc[i][j], pre.bias[j], arow[j], sec[j]) : acc[i][j];
+      if (colsum && mok && n < g.N) add_cs(csum[j], v[j]);
+    }
+    // this row's aux fragments are consumed: fetch row i + PD into the slot (before this row's stores)
+    if (dgelu && i + PD < FI) epi_load_aux_row<T, FI, FJ>(g, m_w, n_w, fr, fq, i + PD, arow);
+    if (wide) {
+      if constexpr (sizeof(TC) == 2) {
 #pragma unroll
         for (int jp = 0; jp < FJ / 2; ++jp) {
           const int nb = n_w + 32 * jp;  // first column of subtile 2jp
-          f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
-          const int na = nb + 4 * fq, nc = nb + 16 + 4 * fq;
-          const bool oka = mok && na < g.N, okc = mok && nc < g.N;
-          f32x4 v0 = oka ? finish(acc[i][2 * jp], m, na, s0) : acc[i][2 * jp];
-          f32x4 v1 = okc ? finish(acc[i][2 * jp + 1], m, nc, s1) : acc[i][2 * jp + 1];
-          if (colsum) {
-            if (oka) add_cs(csum[2 * jp], v0);
-            if (okc) add_cs(csum[2 * jp + 1], v1);
-          }
-          auto pack = [](const f32x4& v) {
-            bf16x4 b = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-            return *reinterpret_cast<uint2*>(&b);
-          };
           auto exchange_store = [&](TC* dst, const f32x4& x0, const f32x4& x1) {
             const uint2 p0 = pack(x0), p1 = pack(x1);
             const uint2 send = odd ? p0 : p1;
@@ -272,26 +330,18 @@ __device__ __forceinline__ void epilogue_tile(f32x4 (&acc)[FI][FJ], const GemmAr
               *reinterpret_cast<uint4*>(dst + (int64_t)m * g.ldc + n) = o;
             }
           };
-          exchange_store(C, v0, v1);
-          if (two) exchange_store(C2, s0, s1);
+          exchange_store(C, v[2 * jp], v[2 * jp + 1]);
+          if (two) exchange_store(C2, sec[2 * jp], sec[2 * jp + 1]);
         }
       }
-      flush_cs();
-      return;
-    }
-  }
+    } else {
 #pragma unroll
-  for (int i = 0; i < FI; ++i) {
-    const int m = m_w + 16 * i + fr;
-#pragma unroll
-    for (int j = 0; j < FJ; ++j) {
-      const int n = n_w + 16 * j + 4 * fq;
-      if (m >= g.M || n >= g.N) continue;
-      f32x4 second = {0.f, 0.f, 0.f, 0.f};
-      f32x4 v = finish(acc[i][j], m, n, second);
-      if (colsum) add_cs(csum[j], v);
-      store4(C + (int64_t)m * g.ldc + n, v);
-      if (two) store4(C2 + (int64_t)m * g.ldc + n, second);
+      for (int j = 0; j < FJ; ++j) {
+        const int n = n_w + 16 * j + 4 * fq;
+        if (!mok || n >= g.N) continue;
+        store4(C + (int64_t)m * g.ldc + n, v[j]);
+        if (two) store4(C2 + (int64_t)m * g.ldc + n, sec[j]);
+      }
     }
   }
   flush_cs();
@@ -301,7 +351,7 @@ __device__ __forceinline__ void epilogue_tile(f32x4 (&acc)[FI][FJ], const GemmAr
 // 16 consecutive columns -> 64-B atomic segments).  Otherwise the MFMA operands are swapped so that each lane
 // owns 4 consecutive columns of one row and can apply the epilogue on / store 8-16 B vectors directly.
 // GL = LDS-DMA staging (only with TA = TB = false and full K tiles).
-template <typename T, typename TC, bool TA, bool TB, bool ACC, bool GL = false>
+template <typename T, typename TC, bool TA, bool TB, bool ACC, bool GL = false, int EPI = -1>
 __global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BK = GT<T>::BK;
@@ -331,6 +381,9 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmArgs g) {
 
   Stager<T, TA> sa;
   Stager<T, TB> sb;
+  EpiPre<T, 4, 4> pre;
+  // (compile-time epilogues only: the run-time variants would hold bias AND aux registers through the K loop)
+  if constexpr (!ACC && EPI >= 0) epi_prefetch<T, 4, 4, EPI>(pre, g, m0 + wm * 64, n0 + wn * 64, lane & 15, lane >> 4);
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -434,7 +487,8 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmArgs g) {
         }
       }
   } else {
-    epilogue_tile<T, TC, 4, 4>(acc, g, m0 + wm * 64, n0 + wn * 64, fr, fq);
+    if constexpr (EPI < 0) epi_prefetch<T, 4, 4, EPI>(pre, g, m0 + wm * 64, n0 + wn * 64, fr, fq);
+    epilogue_tile<T, TC, 4, 4, EPI>(acc, pre, g, m0 + wm * 64, n0 + wn * 64, fr, fq);
   }
 }
 
@@ -466,7 +520,7 @@ __device__ __forceinline__ void r_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <typename TC>
+template <typename TC, int EPI = -1>
 __global__ void __launch_bounds__(256, 2) gemm_r3_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef bf16_t T;
@@ -518,6 +572,8 @@ __global__ void __launch_bounds__(256, 2) gemm_r3_kernel(const GemmArgs g) {
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  EpiPre<T, 8, 4> pre;
+  if constexpr (EPI >= 0) epi_prefetch<T, 8, 4, EPI>(pre, g, m0 + wm * 128, n0 + wn * 64, fr, fq);
 
   const unsigned smem_base = (unsigned)(size_t)((const __attribute__((address_space(3))) char*)smem);
   const unsigned a_off = (unsigned)r_swz(wm * 128 + fr, fq);
@@ -558,7 +614,8 @@ __global__ void __launch_bounds__(256, 2) gemm_r3_kernel(const GemmArgs g) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) mma_frag<T>(bf[j], af[i], acc[i][j]);
   }
-  epilogue_tile<T, TC, 8, 4>(acc, g, m0 + wm * 128, n0 + wn * 64, fr, fq);
+  if constexpr (EPI < 0) epi_prefetch<T, 8, 4, EPI>(pre, g, m0 + wm * 128, n0 + wn * 64, fr, fq);
+  epilogue_tile<T, TC, 8, 4, EPI>(acc, pre, g, m0 + wm * 128, n0 + wn * 64, fr, fq);
 }
 
 // ---- weight-gradient kernel: both operands K-major (dW[M,N] += A[K,M]^T . B[K,N]), bf16, split-K + fp32 atomics ----
@@ -650,19 +707,13 @@ __global__ void __launch_bounds__(256, 2) gemm_tr_kernel(const GemmArgs g) {
   // Fused bias gradient: g.bias != NULL asks for bias[m] += sum_k A[k][m] (the column sums of dY).  That is one more
   // output column with B = 1: extra MFMAs against a constant all-ones fragment (the MFMA pipe is 20 % busy in this
   // kernel), and the separate colsum pass over dY (28 us per Linear) disappears.
-  // The FI row-fragments are dealt round-robin to the 2 x tiles_n waves that share this tile row, so no wave adds
-  // more than ceil(FI / (2 tiles_n)) MFMAs per K-step.
-  unsigned smask = 0;  // wave-uniform: bit i = this wave sums row-fragment i
-  if (g.bias != nullptr) {
-    const int slot = tn * 2 + wn, nslots = g.tiles_n * 2;
+  // The tile's first column block does it (tn == 0); its two waves of equal wm split the FI row-fragments in halves
+  // (two code copies, so the FI / 2 extra accumulators keep compile-time indices).
+  const bool do_sum = g.bias != nullptr && tn == 0;  // wave-uniform
+  constexpr int FH = FI / 2;
+  f32x4 sacc[FH];
 #pragma unroll
-    for (int i = 0; i < FI; ++i)
-      if (i % nslots == slot) smask |= 1u << i;
-  }
-  const bool do_sum = smask != 0;
-  f32x4 sacc[FI];
-#pragma unroll
-  for (int i = 0; i < FI; ++i) sacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < FH; ++i) sacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   const uint4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};  // 8 x bf16(1.0)
 
   // ---- transposed fragment reads: lane = 16 g + 4 q + p supplies row 8 g + 4 t + q, columns 4 p .. 4 p + 3 of the
@@ -712,34 +763,38 @@ __global__ void __launch_bounds__(256, 2) gemm_tr_kernel(const GemmArgs g) {
           mma_frag<T>(af[i], bf[j], acc[i][j]);
       }
     if (do_sum) {
+      if (wn == 0) {
 #pragma unroll
-      for (int i = 0; i < FI; ++i) {
-        if (!((smask >> i) & 1)) continue;
-        if constexpr (PART)
-          mma_frag<T>(ones, af[i], sacc[i]);
-        else
-          mma_frag<T>(af[i], ones, sacc[i]);
+        for (int i = 0; i < FH; ++i) {
+          if constexpr (PART) mma_frag<T>(ones, af[i], sacc[i]);
+          else mma_frag<T>(af[i], ones, sacc[i]);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < FH; ++i) {
+          if constexpr (PART) mma_frag<T>(ones, af[FH + i], sacc[i]);
+          else mma_frag<T>(af[FH + i], ones, sacc[i]);
+        }
       }
     }
   }
   if (do_sum) {
     float* bg = const_cast<float*>(g.bias);
 #pragma unroll
-    for (int i = 0; i < FI; ++i) {
-      if (!((smask >> i) & 1)) continue;
+    for (int i = 0; i < FH; ++i) {
+      const int mb = m0 + wm * 16 * FI + 16 * (wn * FH + i);
       if constexpr (PART) {  // D[n][m]: column m = fr on the lane, every row equal
-        const int m = m0 + wm * 16 * FI + 16 * i + fr;
+        const int m = mb + fr;
         if (fq == 0 && m < g.M) atomicAdd(bg + m, sacc[i][0]);
       } else {  // D[m][n]: rows 4 fq + r in the registers, every column equal
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int m = m0 + wm * 16 * FI + 16 * i + 4 * fq + r;
+          const int m = mb + 4 * fq + r;
           if (fr == 0 && m < g.M) atomicAdd(bg + m, sacc[i][r]);
         }
       }
     }
   }
-
   if constexpr (PART) {
     float* P = static_cast<float*>(g.C2) + (int64_t)zsl * g.M * g.N;
 #pragma unroll
@@ -780,9 +835,9 @@ struct GemmProf {
 };
 GemmProf g_prof;
 
-template <typename T, typename TC, bool TA, bool TB, bool ACC, bool GL = false>
+template <typename T, typename TC, bool TA, bool TB, bool ACC, bool GL = false, int EPI = -1>
 int launch(const GemmArgs& g, int split, hipStream_t st) {
-  auto kern = gemm_kernel<T, TC, TA, TB, ACC, GL>;
+  auto kern = gemm_kernel<T, TC, TA, TB, ACC, GL, EPI>;
   static bool attr_done = false;  // per instantiation
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -803,9 +858,9 @@ int launch(const GemmArgs& g, int split, hipStream_t st) {
   return UWU_OK;
 }
 
-template <typename TC>
+template <typename TC, int EPI = -1>
 int launch_r3(GemmArgs g, hipStream_t st) {
-  auto kern = gemm_r3_kernel<TC>;
+  auto kern = gemm_r3_kernel<TC, EPI>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -945,14 +1000,35 @@ int dispatch_trans(const GemmArgs& g, int ta, int tb, bool acc, int split, hipSt
     uwu_set_error("gemm: ACCUM epilogue needs fp32 C and (transA,transB) in {(0,0),(0,1),(1,1)}");
     return UWU_EINVAL;
   }
+  constexpr bool hot = sizeof(T) == 2 && sizeof(TC) == 2;  // bf16 in / bf16 out: compile-time epilogues
   if (ta == 0 && tb == 0) {
     if constexpr (sizeof(T) == 2) {
-      if (use_r3(g)) return launch_r3<TC>(g, st);
+      if (use_r3(g)) {
+        if constexpr (hot) {
+          if (g.epi == UWU_EPI_NONE) return launch_r3<TC, UWU_EPI_NONE>(g, st);
+          if (g.epi == UWU_EPI_BIAS) return launch_r3<TC, UWU_EPI_BIAS>(g, st);
+          if (g.epi == UWU_EPI_BIAS_GELU) return launch_r3<TC, UWU_EPI_BIAS_GELU>(g, st);
+        }
+        return launch_r3<TC>(g, st);
+      }
     }
-    if (g.K % GT<T>::BK == 0 && !no_glds()) return launch<T, TC, false, false, false, true>(g, split, st);
+    if (g.K % GT<T>::BK == 0 && !no_glds()) {
+      if constexpr (hot) {
+        if (g.epi == UWU_EPI_NONE) return launch<T, TC, false, false, false, true, UWU_EPI_NONE>(g, split, st);
+        if (g.epi == UWU_EPI_BIAS) return launch<T, TC, false, false, false, true, UWU_EPI_BIAS>(g, split, st);
+        if (g.epi == UWU_EPI_BIAS_GELU) return launch<T, TC, false, false, false, true, UWU_EPI_BIAS_GELU>(g, split, st);
+      }
+      return launch<T, TC, false, false, false, true>(g, split, st);
+    }
     return launch<T, TC, false, false, false>(g, split, st);
   }
-  if (ta == 0 && tb == 1) return launch<T, TC, false, true, false>(g, split, st);
+  if (ta == 0 && tb == 1) {
+    if constexpr (hot) {
+      if (g.epi == UWU_EPI_NONE) return launch<T, TC, false, true, false, false, UWU_EPI_NONE>(g, split, st);
+      if (g.epi == UWU_EPI_DGELU) return launch<T, TC, false, true, false, false, UWU_EPI_DGELU>(g, split, st);
+    }
+    return launch<T, TC, false, true, false>(g, split, st);
+  }
   if (ta == 1 && tb == 1) return launch<T, TC, true, true, false>(g, split, st);
   uwu_set_error("gemm: (transA=1, transB=0) is not instantiated");
   return UWU_EINVAL;
