@@ -9,20 +9,21 @@ import sys
 
 
 def load(dirname, counter):
-    f = glob.glob(f"{dirname}/*/*counter_collection.csv")[0]
+    f = glob.glob(f"{dirname}/**/*counter_collection.csv", recursive=True)[0]
     tot, n = 0.0, 0
     per = {}
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
             continue
         k = r["Kernel_Name"]
-        if "gemm" not in k:
+        reduce = "splitk_reduce" in k  # second kernel of a weight-gradient launch: bytes count, launches do not
+        if "gemm" not in k and not reduce:
             continue
-        fam = "fp32" if ("IffLb" in k or "<float" in k) else "bf16"
+        fam = "fp32" if ("IffLb" in k or "<float" in k or "gemm_r3_kernelIf" in k) else "bf16"
         if fam != "bf16":
             continue
         tot += float(r["Counter_Value"])
-        n += 1
+        n += 0 if reduce else 1
         per[k[:70]] = per.get(k[:70], 0) + float(r["Counter_Value"])
     return tot, n, per
 
@@ -31,7 +32,7 @@ fetch, nf, pf = load(sys.argv[1], "FETCH_SIZE")
 write, nw, pw = load(sys.argv[2], "WRITE_SIZE")
 out = {
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline",
-    "kernel_family": "bf16 gemm_kernel (fwd + dgrad + wgrad launches)",
+    "kernel_family": "bf16 MFMA GEMM family: gemm_kernel / gemm_r3_kernel / gemm_tr_kernel (+ splitk_reduce bytes), fwd + dgrad + wgrad launches",
     "launches": nf,
     "fetch_kib_sum_raw": fetch, "write_kib_sum": write,
     "hbm_bytes_per_launch": (2.0 * fetch / nf + write / nw) * 1024.0,

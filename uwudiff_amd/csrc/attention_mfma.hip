@@ -81,8 +81,17 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_mfma(const MArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 16384];  // 2 stages x (K 8 KB | V^T 8 KB)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int bh = blockIdx.y, b = bh / a.H, hd = bh - b * a.H;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  // 1-D grid, XCD-aware: workgroups w and w+8 share an XCD (round-robin dispatch), so every XCD takes a contiguous
+  // run of logical ids (query tile fastest) and the query tiles of one head read its K / V through the same L2.
+  const int ntq = (a.T + 127) / 128, total = ntq * a.B * a.H;
+  int lid;
+  {
+    const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+    const int q = total >> 3, rm = total & 7;
+    lid = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + loc;
+  }
+  const int bh = lid / ntq, b = bh / a.H, hd = bh - b * a.H;
+  const int q0 = (lid - bh * ntq) * 128 + wave * 32;
   const bool active = q0 < a.T;  // wave-uniform
   const bf16_t* qb = a.q + (int64_t)b * a.T * a.ldq + hd * 64;
   const bf16_t* kb = a.k + (int64_t)b * a.T * a.ldk + hd * 64;
@@ -413,7 +422,7 @@ int uwu_attn_mfma_fwd(const void* q, const void* k, const void* v, void* o, floa
   MArgs a{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)o; a.lse = lse;
   a.B = B; a.T = T; a.H = H; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.scale = scale;
-  hipLaunchKernelGGL(attn_fwd_mfma, dim3((T + 127) / 128, B * H), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(attn_fwd_mfma, dim3(((T + 127) / 128) * B * H), dim3(256), 0, st, a);
   UWU_LAUNCH_CHECK("attention_fwd(mfma)");
   return UWU_OK;
 }

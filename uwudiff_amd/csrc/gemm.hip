@@ -224,9 +224,10 @@ __device__ __forceinline__ void epi_prefetch(EpiPre<T, FI, FJ>& pre, const GemmA
   }
 }
 
+// cs_lds: >= 4 * 16 * FJ floats of LDS, free once every wave has left the K loop (dGELU column sums only).
 template <typename T, typename TC, int FI, int FJ, int EPI = -1>
 __device__ __forceinline__ void epilogue_tile(f32x4 (&acc)[FI][FJ], EpiPre<T, FI, FJ>& pre, const GemmArgs& g, int m_w,
-                                              int n_w, int fr, int fq) {
+                                              int n_w, int fr, int fq, float* cs_lds, int wm, int wn) {
   TC* C = static_cast<TC*>(g.C);
   TC* C2 = static_cast<TC*>(g.C2);
   const int epi = EPI >= 0 ? EPI : g.epi;
@@ -264,16 +265,15 @@ __device__ __forceinline__ void epilogue_tile(f32x4 (&acc)[FI][FJ], EpiPre<T, FI
   f32x4 csum[FJ];
 #pragma unroll
   for (int j = 0; j < FJ; ++j) csum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto add_cs = [&](f32x4& acc_, const f32x4& v) {
-    if constexpr (sizeof(TC) == 2) {  // sum what the consumers read: the bf16-rounded values
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc_[e] += (float)(bf16_t)v[e];
-    } else {
-      acc_ = acc_ + v;
-    }
-  };
+  // (the fp32 values before rounding to the output type: one add per element, and closer to the fp32 reference)
+  auto add_cs = [&](f32x4& acc_, const f32x4& v) { acc_ = acc_ + v; };
+  // Global fp32 atomics are paid per wave-INSTRUCTION (~50 ns each per CU), not per lane: one atomic per (wave,
+  // fragment, element) with 4 live lanes each cost 77 us per launch on the fc2 input-gradient.  So the four waves
+  // first meet in LDS (the two wm halves cover the same columns) and 32 FJ lanes issue ONE atomic each.
   auto flush_cs = [&]() {
-    if (!colsum) return;
+    if (!colsum) return;  // uniform
+    constexpr int BNT = 2 * 16 * FJ;  // columns of the workgroup tile
+    __syncthreads();                  // every wave has left the K loop: its LDS is free
 #pragma unroll
     for (int j = 0; j < FJ; ++j) {
       f32x4 v = csum[j];
@@ -281,12 +281,11 @@ __device__ __forceinline__ void epilogue_tile(f32x4 (&acc)[FI][FJ], EpiPre<T, FI
       for (int o = 1; o < 16; o <<= 1)
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += __shfl_xor(v[e], o, 64);
-      const int n = n_w + 16 * j + 4 * fq;
-      if (fr == 0 && n < g.N) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) atomicAdd(colsum + n + e, v[e]);
-      }
+      if (fr == 0) store4(cs_lds + wm * BNT + wn * 16 * FJ + 16 * j + 4 * fq, v);
     }
+    __syncthreads();
+    const int t = threadIdx.x, n = n_w - wn * 16 * FJ + t;
+    if (t < BNT && n < g.N) atomicAdd(colsum + n, cs_lds[t] + cs_lds[BNT + t]);
   };
   // bf16 output: stores are instruction-bound (fp32 output of the same tile costs the same per store), so
   // pair lanes l and l^16 (column groups fq, fq^1) and swap half of two neighbouring 16-column subtiles:
@@ -488,7 +487,7 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmArgs g) {
       }
   } else {
     if constexpr (EPI < 0) epi_prefetch<T, 4, 4, EPI>(pre, g, m0 + wm * 64, n0 + wn * 64, fr, fq);
-    epilogue_tile<T, TC, 4, 4, EPI>(acc, pre, g, m0 + wm * 64, n0 + wn * 64, fr, fq);
+    epilogue_tile<T, TC, 4, 4, EPI>(acc, pre, g, m0 + wm * 64, n0 + wn * 64, fr, fq, reinterpret_cast<float*>(smem), wm, wn);
   }
 }
 
@@ -615,7 +614,7 @@ __global__ void __launch_bounds__(256, 2) gemm_r3_kernel(const GemmArgs g) {
       for (int j = 0; j < 4; ++j) mma_frag<T>(bf[j], af[i], acc[i][j]);
   }
   if constexpr (EPI < 0) epi_prefetch<T, 8, 4, EPI>(pre, g, m0 + wm * 128, n0 + wn * 64, fr, fq);
-  epilogue_tile<T, TC, 8, 4, EPI>(acc, pre, g, m0 + wm * 128, n0 + wn * 64, fr, fq);
+  epilogue_tile<T, TC, 8, 4, EPI>(acc, pre, g, m0 + wm * 128, n0 + wn * 64, fr, fq, reinterpret_cast<float*>(smem), wm, wn);
 }
 
 // ---- weight-gradient kernel: both operands K-major (dW[M,N] += A[K,M]^T . B[K,N]), bf16, split-K + fp32 atomics ----
@@ -1041,12 +1040,6 @@ bool uwu_gemm_ring_ok(int K, int dtype);
 int uwu_gemm_ring(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux, int M, int N,
                   int K, int lda, int ldb, int ldc, int ldaux, int dtype, int c_dtype, int epilogue, hipStream_t st);
 
-// 256x384 panel kernel for the token-parallel bf16 Linears (gemm_panel.hip)
-bool uwu_gemm_panel_ok(int M, int N, int K, int lda, int ldb, int ldc, int ldaux, int dtype, int c_dtype, int epilogue,
-                       const void* A, const void* B, const void* C, const void* C2, const void* aux);
-int uwu_gemm_panel(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux, int M, int N,
-                   int K, int lda, int ldb, int ldc, int ldaux, int epilogue, hipStream_t st);
-
 extern "C" int uwu_gemm(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux, int M,
                         int N, int K, int lda, int ldb, int ldc, int ldaux, int transA, int transB, int dtype,
                         int c_dtype, int epilogue, int split_k, void* stream) {
@@ -1078,19 +1071,6 @@ extern "C" int uwu_gemm(const void* A, const void* B, void* C, void* C2, const f
                     "gemm: aux missing/misaligned");
   } else {
     UWU_CHECK_ARG(c_dtype == UWU_F32 && ldc >= N, "gemm: ACCUM needs fp32 C");
-  }
-  if (!transA && !transB && !acc &&
-      uwu_gemm_panel_ok(M, N, K, lda, ldb, ldc, ldaux, dtype, c_dtype, epilogue, A, B, C, C2, aux)) {
-    const bool rec = g_prof.on && g_prof.n < GemmProf::MAXP;
-    if (rec) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], (hipStream_t)stream);
-    int rc = uwu_gemm_panel(A, B, C, C2, bias, aux, M, N, K, lda, ldb, ldc, ldaux, epilogue, (hipStream_t)stream);
-    if (rec) {
-      (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], (hipStream_t)stream);
-      g_prof.flops[g_prof.n] = 2.0 * M * N * K;
-      g_prof.kind[g_prof.n] = 0;
-      ++g_prof.n;
-    }
-    return rc;
   }
   if (!transA && !transB && !acc && uwu_gemm_ring_ok(K, dtype)) {
     const bool rec = g_prof.on && g_prof.n < GemmProf::MAXP;
