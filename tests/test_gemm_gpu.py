@@ -119,8 +119,8 @@ def test_gemm_rejects_bad_shapes():
         ops.gemm(a, b)
 
 
-# ---- 256x128-tile kernel (gemm_r3_kernel): picked by the host for K-contiguous bf16 operands once there are >= 1024
-# tiles.  It issues the same sequence of 16x16x32 MFMAs per output as the 128x128 kernel, so the two must agree bit
+# ---- ring kernel (gemm_r3_kernel): picked by the host for K-contiguous bf16 operands once there are >= 1024 tiles of
+# 256x128.  It issues the same sequence of 16x16x32 MFMAs per output as the 128x128 kernel, so the two must agree bit
 # for bit on any operands; UWU_GEMM_R3=0 (read per call) keeps a call on the 128x128 kernel, which the tests above
 # pin to the CPU fp64 matmul.
 R3_SHAPES = [(65536, 1152, 384), (52000, 648, 160), (262144, 128, 96), (33000, 1536, 1536)]
@@ -233,3 +233,25 @@ def test_gemm_wgrad_scratch_path(M, N, K):
     ops.gemm_wgrad(a.float(), b.float(), dw, bias_grad=db)
     assert torch.equal(dw, want - 2.0)
     assert torch.equal(db, bsum)
+
+
+# ---- ring kernel with the K-major weight read through ds_read_b64_tr_b16 (input gradients): 128x128 (N = 384
+# shapes) and 256x128 (wide N) variants must equal gemm_kernel's register-transposing path bit for bit.
+@pytest.mark.parametrize("M,N,K", [(65536, 384, 1152), (65536, 1536, 384), (40000, 392, 160), (70000, 1160, 96)])
+def test_gemm_r3_input_gradient_matches_128_kernel(M, N, K, monkeypatch):
+    from uwudiff_amd import lib as L
+    from uwudiff_amd import ops
+
+    a, b = _operands(M, N, K, False, True, torch.bfloat16, ints=False, seed=21)
+    ref, got = _both(monkeypatch, lambda: ops.gemm(a, b, trans_b=True))
+    assert torch.equal(ref, got)
+    u = (torch.randn(M, N, generator=torch.Generator().manual_seed(22)) * 1.5).bfloat16().cuda()
+
+    def run():
+        cs = torch.zeros(N, device="cuda")
+        out = ops.gemm(a, b, trans_b=True, aux=u, epilogue=L.EPI_DGELU, out2=cs)
+        return (out[0] if isinstance(out, tuple) else out), cs
+
+    (d0, s0), (d1, s1) = _both(monkeypatch, run)
+    assert torch.equal(d0, d1)
+    torch.testing.assert_close(s0, s1, rtol=1e-3, atol=0.5)  # fp32 atomics: order differs

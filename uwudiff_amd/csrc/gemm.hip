@@ -491,20 +491,22 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmArgs g) {
   }
 }
 
-// ---- 256x128-tile kernel for the token-parallel Linears (K-contiguous bf16 operands) --------------------------
+// ---- ring kernel for the token-parallel Linears: forward (B = W [N,K]) and input gradient (B = W [K,N]) ---------
 // PMC on the 128x128 kernel (65536x1152x384): the L2 -> LDS intake (903 MB per launch at ~12 TB/s chip-wide) is the
-// longest phase and the waves are parked 46 % of their cycles on the 2-stage pipeline.  Same two-workgroups-per-CU
-// structure (independent barriers: one workgroup's MFMAs run under the other's waits, and tile ends / store bursts
-// stagger by themselves), but: 256x128 tile (85 flop per L2 byte instead of 64), K-step 32 = 64-byte rows, a
-// 3-stage LDS-DMA ring (2 x 24 KB in flight per workgroup, 72 KB -> two workgroups per CU), counted vmcnt waits, one
-// barrier per K-step, fragment reads as inline asm (see lds_read128_asm).
-// Wave tile 128x64 = 8x4 accumulators of v_mfma_f32_16x16x32_bf16; LDS image [A rows 0..255 | B rows 0..127] x 64 B
-// with 16-byte chunk c of row r at position c ^ G[(r>>2)&3], G = {0,3,2,1} (conflict-free in the four ds_read_b128
-// lane groups); the DMA writes lane-linear, so the swizzle is applied to the per-lane source address.
-constexpr int R_BM = 256, R_BN = 128, R_ROWB = 64, R_NST = 3;
-constexpr int R_A_BYTES = R_BM * R_ROWB;         // 16 KB
-constexpr int R_STAGE = (R_BM + R_BN) * R_ROWB;  // 24 KB
-constexpr int R_PS = (R_BM + R_BN) / 16 / 4;     // 6 DMA instructions per wave per K-step
+// longest phase and the waves are parked 46 % of their cycles on the 2-stage pipeline; its input-gradient path stages
+// the K-major weight through registers (v_perm + ds_write_b64: 20 % LDS conflicts, 5x more VALU than MFMA
+// instructions).  Same two-workgroups-per-CU structure (independent barriers: one workgroup's MFMAs run under the
+// other's waits, and tile ends / store bursts stagger by themselves), but:
+//   * K-step 32, everything staged by LDS-DMA into a ring (counted vmcnt waits, one barrier per K-step, fragment
+//     reads as inline asm, see lds_read128_asm): FI = 8 -> 256x128 tile (85 flop per L2 byte instead of 64), 3 stages
+//     of 24 KB; FI = 4 -> 128x128 tile, 4 stages of 16 KB;
+//   * A (activations / output gradients, K-contiguous): image [rows][64 B], 16-byte chunk c of row r at position
+//     c ^ G[(r>>2)&3], G = {0,3,2,1} (conflict-free in the four ds_read_b128 lane groups); the DMA writes lane-linear,
+//     so the swizzle is applied to the per-lane source address;
+//   * B: TB = 0 the same image (weight rows are K-contiguous); TB = 1 the K-major weight goes to LDS untouched as a
+//     [32 k][128 n] sub-image and the fragments are gathered by ds_read_b64_tr_b16 (layout: gemm_tr_kernel below).
+constexpr int R_ROWB = 64;
+constexpr int R_BSUB = 32 * 256;  // B part of a stage: 128 rows x 64 B (TB = 0) or 32 k-rows x 256 B (TB = 1)
 
 __device__ __forceinline__ int r_gsw(int row) { return (0 - (row >> 2)) & 3; }
 __device__ __forceinline__ int r_swz(int row, int chunk) { return row * R_ROWB + (((chunk ^ r_gsw(row)) & 3) << 4); }
@@ -518,11 +520,34 @@ template <int N>
 __device__ __forceinline__ void r_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+// transposing LDS read (4 x 16 block of b16 per 16 lanes, delivered column-major); EXEC must be all ones
+template <int OFF>
+__device__ __forceinline__ uint2 t_read_tr(unsigned addr) {
+  typedef unsigned tu32x2 __attribute__((ext_vector_type(2)));
+  tu32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return uint2{v[0], v[1]};
+}
+// Byte offset inside a [32 k][128 x] sub-image that lane = 16 g + 4 q + p supplies to transposed read t (0 / 1) of
+// the fragment whose first column is 8 * xb8: row 8 g + 4 t + q, columns 4 p .. 4 p + 3.  Chunk ch of k-row r sits
+// at 256 r + 16 (ch ^ (((r & 3) << 2) | ((r >> 2) & 3)))  (cdna_hip_programming.md T10, image (b)); fragment f of
+// the wave only flips chunk bits: address ^ (f << 5).
+__device__ __forceinline__ unsigned tr_lane_base(int lane, int t, int xb8) {
+  const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+  const int krow = 8 * tg + 4 * t + tq;
+  const int f = (tq << 2) | ((2 * tg + t) & 3);
+  return (unsigned)(256 * krow + 16 * ((xb8 + (tp >> 1)) ^ f) + 8 * (tp & 1));
+}
 
-template <typename TC, int EPI = -1>
+template <typename TC, int EPI, bool TB, int FI>
 __global__ void __launch_bounds__(256, 2) gemm_r3_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef bf16_t T;
+  static_assert(FI == 8 || FI == 4, "256x128 or 128x128");
+  constexpr int RBM = 32 * FI, RBN = 128;
+  constexpr int A_BYTES = RBM * R_ROWB, STAGE = A_BYTES + R_BSUB;
+  constexpr int NST = FI == 8 ? 3 : 4;
+  constexpr int QA = FI / 2, PS = QA + 2;  // DMA instructions per wave per K-step: A pieces + 2 B pieces
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int fr = lane & 15, fq = lane >> 4;
@@ -534,87 +559,115 @@ __global__ void __launch_bounds__(256, 2) gemm_r3_kernel(const GemmArgs g) {
     tile = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + loc;
   }
   const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
-  const int m0 = tm * R_BM, n0 = tn * R_BN;
+  const int m0 = tm * RBM, n0 = tn * RBN;
   const int nk = g.K >> 5;
 
-  // per-lane DMA source rows (clamped: products of rows past M / N are never stored)
+  // per-lane DMA sources (rows / columns past the operand are clamped: their products are never stored)
   const int prow = lane >> 2;
   const int csrc = ((lane & 3) ^ r_gsw(prow)) & 3;  // logical chunk that must land at position lane & 3
-  const T* pa[4];
+  const T* pa[QA];
   const T* pb[2];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < QA; ++q) {
     int row = m0 + 16 * (wave + 4 * q) + prow;
     if (row >= g.M) row = g.M - 1;
     pa[q] = static_cast<const T*>(g.A) + (int64_t)row * g.lda + 8 * csrc;
   }
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
-    int row = n0 + 16 * (wave + 4 * q) + prow;
-    if (row >= g.N) row = g.N - 1;
-    pb[q] = static_cast<const T*>(g.B) + (int64_t)row * g.ldb + 8 * csrc;
+    if constexpr (!TB) {
+      int row = n0 + 16 * (wave + 4 * q) + prow;
+      if (row >= g.N) row = g.N - 1;
+      pb[q] = static_cast<const T*>(g.B) + (int64_t)row * g.ldb + 8 * csrc;
+    } else {  // piece P = wave + 4 q: k-rows 4 P .. 4 P + 3 of the sub-image, 256 B each
+      const int drow = lane >> 4;
+      const int dchunk = (lane & 15) ^ (((drow & 3) << 2) | (wave & 3));  // (P & 3) == (wave & 3)
+      int x = n0 + 8 * dchunk;
+      if (x > g.N - 8) x = g.N - 8;
+      pb[q] = static_cast<const T*>(g.B) + (int64_t)(4 * (wave + 4 * q) + drow) * g.ldb + x;
+    }
   }
+  const int64_t bstep = TB ? (int64_t)32 * g.ldb : 32;
   auto issue = [&](int s) {
-    char* st = smem + (s % R_NST) * R_STAGE + wave * 1024;
+    char* st = smem + (s % NST) * STAGE + wave * 1024;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < QA; ++q)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[q] + s * 32),
                                        (__attribute__((address_space(3))) void*)(st + q * 4096), 16, 0, 0);
 #pragma unroll
     for (int q = 0; q < 2; ++q)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb[q] + s * 32),
-                                       (__attribute__((address_space(3))) void*)(st + R_A_BYTES + q * 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb[q] + s * bstep),
+                                       (__attribute__((address_space(3))) void*)(st + A_BYTES + q * 4096), 16, 0, 0);
   };
 
-  f32x4 acc[8][4];
+  f32x4 acc[FI][4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < FI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  EpiPre<T, 8, 4> pre;
-  if constexpr (EPI >= 0) epi_prefetch<T, 8, 4, EPI>(pre, g, m0 + wm * 128, n0 + wn * 64, fr, fq);
+  EpiPre<T, FI, 4> pre;
+  if constexpr (EPI >= 0) epi_prefetch<T, FI, 4, EPI>(pre, g, m0 + wm * 16 * FI, n0 + wn * 64, fr, fq);
 
   const unsigned smem_base = (unsigned)(size_t)((const __attribute__((address_space(3))) char*)smem);
-  const unsigned a_off = (unsigned)r_swz(wm * 128 + fr, fq);
-  const unsigned b_off = (unsigned)(R_A_BYTES + r_swz(wn * 64 + fr, fq));
+  const unsigned a_off = (unsigned)r_swz(wm * 16 * FI + fr, fq);
+  const unsigned b_off = (unsigned)(A_BYTES + r_swz(wn * 64 + fr, fq));                     // TB = 0
+  const unsigned b_t0 = A_BYTES + tr_lane_base(lane, 0, 8 * wn), b_t1 = A_BYTES + tr_lane_base(lane, 1, 8 * wn);  // TB = 1
 
   issue(0);
   if (nk > 1) issue(1);
+  if (NST > 3 && nk > 2) issue(2);
   for (int s = 0; s < nk; ++s) {
-    // K-step s has landed (this wave's pieces); the younger operations are step s+1's pieces
-    if (s + 1 < nk) r_wait_vm<R_PS>(); else r_wait_vm<0>();
-    __builtin_amdgcn_s_barrier();  // ... everybody's; and everybody is done reading stage (s-1) % 3
-    if (s + 2 < nk) issue(s + 2);  // -> stage (s+2) % 3 == (s-1) % 3
-    const unsigned sa = smem_base + (unsigned)((s % R_NST) * R_STAGE) + a_off;
-    const unsigned sb = smem_base + (unsigned)((s % R_NST) * R_STAGE) + b_off;
-    uint4 bf[4], af[8];
-    bf[0] = r_read128<0>(sb);
-    bf[1] = r_read128<1024>(sb);
-    bf[2] = r_read128<2048>(sb);
-    bf[3] = r_read128<3072>(sb);
+    // K-step s has landed (this wave's pieces); the younger operations are the pieces of the steps issued after it
+    const int ahead = nk - 1 - s < NST - 2 ? nk - 1 - s : NST - 2;
+    if (ahead >= 2) r_wait_vm<2 * PS>();
+    else if (ahead == 1) r_wait_vm<PS>();
+    else r_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();              // ... everybody's; and everybody is done reading stage (s-1) % NST
+    if (s + NST - 1 < nk) issue(s + NST - 1);  // -> stage (s-1) % NST
+    const unsigned sb0 = smem_base + (unsigned)((s % NST) * STAGE);
+    uint4 bf[4], af[FI];
+    if constexpr (!TB) {
+      bf[0] = r_read128<0>(sb0 + b_off);
+      bf[1] = r_read128<1024>(sb0 + b_off);
+      bf[2] = r_read128<2048>(sb0 + b_off);
+      bf[3] = r_read128<3072>(sb0 + b_off);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint2 lo = t_read_tr<0>(sb0 + (b_t0 ^ (unsigned)(j << 5)));
+        const uint2 hi = t_read_tr<0>(sb0 + (b_t1 ^ (unsigned)(j << 5)));
+        bf[j] = uint4{lo.x, lo.y, hi.x, hi.y};
+      }
+    }
+    const unsigned sa = sb0 + a_off;
     af[0] = r_read128<0>(sa);
     af[1] = r_read128<1024>(sa);
     af[2] = r_read128<2048>(sa);
     af[3] = r_read128<3072>(sa);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    af[4] = r_read128<4096>(sa);
-    af[5] = r_read128<5120>(sa);
-    af[6] = r_read128<6144>(sa);
-    af[7] = r_read128<7168>(sa);
+    if constexpr (FI == 8) {
+      af[4] = r_read128<4096>(sa);
+      af[5] = r_read128<5120>(sa);
+      af[6] = r_read128<6144>(sa);
+      af[7] = r_read128<7168>(sa);
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) mma_frag<T>(bf[j], af[i], acc[i][j]);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (FI == 8) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 4; i < 8; ++i)
+      for (int i = 4; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) mma_frag<T>(bf[j], af[i], acc[i][j]);
+        for (int j = 0; j < 4; ++j) mma_frag<T>(bf[j], af[i], acc[i][j]);
+    }
   }
-  if constexpr (EPI < 0) epi_prefetch<T, 8, 4, EPI>(pre, g, m0 + wm * 128, n0 + wn * 64, fr, fq);
-  epilogue_tile<T, TC, 8, 4, EPI>(acc, pre, g, m0 + wm * 128, n0 + wn * 64, fr, fq, reinterpret_cast<float*>(smem), wm, wn);
+  if constexpr (EPI < 0) epi_prefetch<T, FI, 4, EPI>(pre, g, m0 + wm * 16 * FI, n0 + wn * 64, fr, fq);
+  epilogue_tile<T, TC, FI, 4, EPI>(acc, pre, g, m0 + wm * 16 * FI, n0 + wn * 64, fr, fq, reinterpret_cast<float*>(smem),
+                                   wm, wn);
 }
 
 // ---- weight-gradient kernel: both operands K-major (dW[M,N] += A[K,M]^T . B[K,N]), bf16, split-K + fp32 atomics ----
@@ -632,13 +685,6 @@ constexpr int T_STAGE = 3 * T_SUB;     // A sub-images then B sub-images (2 + 1 
 constexpr int T_NST = 3;
 constexpr int T_PS = 6;                // DMA instructions per wave per K-step (24 pieces of 4 rows / 4 waves)
 
-template <int OFF>
-__device__ __forceinline__ uint2 t_read_tr(unsigned addr) {
-  typedef unsigned tu32x2 __attribute__((ext_vector_type(2)));
-  tu32x2 v;
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
-  return uint2{v[0], v[1]};
-}
 
 // PART: the split-K partial goes to a dense scratch [split][M][N] with plain 16-byte stores (swapped MFMA operands:
 // a lane owns 4 consecutive columns) and splitk_reduce_kernel adds the slices to C -- global fp32 atomics move only
@@ -857,20 +903,20 @@ int launch(const GemmArgs& g, int split, hipStream_t st) {
   return UWU_OK;
 }
 
-template <typename TC, int EPI = -1>
+template <typename TC, int EPI, bool TB, int FI>
 int launch_r3(GemmArgs g, hipStream_t st) {
-  auto kern = gemm_r3_kernel<TC, EPI>;
+  auto kern = gemm_r3_kernel<TC, EPI, TB, FI>;
+  constexpr int LDS = (FI == 8 ? 3 : 4) * (32 * FI * R_ROWB + R_BSUB);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              R_NST * R_STAGE);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_done = true;
   }
-  g.tiles_m = (g.M + R_BM - 1) / R_BM;
-  g.tiles_n = (g.N + R_BN - 1) / R_BN;
+  g.tiles_m = (g.M + 32 * FI - 1) / (32 * FI);
+  g.tiles_n = (g.N + 127) / 128;
   const bool rec = g_prof.on && g_prof.n < GemmProf::MAXP;
   if (rec) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], st);
-  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(256), R_NST * R_STAGE, st, g);
+  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(256), LDS, st, g);
   if (rec) {
     (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st);
     g_prof.flops[g_prof.n] = 2.0 * g.M * g.N * g.K;
@@ -961,13 +1007,20 @@ int pick_tr(const GemmArgs& g) {
   return w1 <= w2 ? 1 : 2;
 }
 
-// the 256x128 kernel pays off on the wide-N Linears (65536x1152x384: 92 us against 104; x1536: 128 against 147); with
-// 768 tiles (N = 384) the second round of 512 workgroup slots is half empty and the 128x128 kernel stays ahead
-bool use_r3(const GemmArgs& g) {
+// Ring kernel choice for bf16 operands with A K-contiguous: 0 = gemm_kernel, 8 = 256x128, 4 = 128x128.
+// 256x128 pays off on the wide-N Linears (65536x1152x384: 84 us against 97; x1536: 108 against 132); with 768 tiles
+// (N = 384) the second round of 512 workgroup slots would be half empty.  The 128x128 ring (4 stages) replaces
+// gemm_kernel's register-staged input-gradient path (K-major weight: qkv dgrad 96 -> 70 us, fc1 dgrad 111 -> 90).
+int pick_r3(const GemmArgs& g, bool tb) {
   const char* e = getenv("UWU_GEMM_R3");  // "0": off (A/B comparisons)
-  if (e && e[0] == '0') return false;
-  const int64_t tiles = (int64_t)((g.M + R_BM - 1) / R_BM) * ((g.N + R_BN - 1) / R_BN);
-  return g.K % 32 == 0 && g.K >= 96 && tiles >= 1024;
+  if (e && e[0] == '0') return 0;
+  if (g.K % 32 || g.K < 96) return 0;
+  if ((((uintptr_t)g.A | (uintptr_t)g.B) & 15) || g.lda % 8 || g.ldb % 8) return 0;
+  if (tb && (g.N % 8 || g.N < 8)) return 0;
+  const int64_t t8 = (int64_t)((g.M + 255) / 256) * ((g.N + 127) / 128);
+  if (t8 >= 1024) return 8;
+  const int64_t t4 = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128);
+  return (tb && t4 >= 512) ? 4 : 0;  // K-contiguous B at N = 384: gemm_kernel's 128-byte rows measured faster (proj 35 vs 43 us)
 }
 
 bool no_glds() {
@@ -1002,13 +1055,14 @@ int dispatch_trans(const GemmArgs& g, int ta, int tb, bool acc, int split, hipSt
   constexpr bool hot = sizeof(T) == 2 && sizeof(TC) == 2;  // bf16 in / bf16 out: compile-time epilogues
   if (ta == 0 && tb == 0) {
     if constexpr (sizeof(T) == 2) {
-      if (use_r3(g)) {
+      const int r3 = pick_r3(g, false);
+      if (r3 == 8) {
         if constexpr (hot) {
-          if (g.epi == UWU_EPI_NONE) return launch_r3<TC, UWU_EPI_NONE>(g, st);
-          if (g.epi == UWU_EPI_BIAS) return launch_r3<TC, UWU_EPI_BIAS>(g, st);
-          if (g.epi == UWU_EPI_BIAS_GELU) return launch_r3<TC, UWU_EPI_BIAS_GELU>(g, st);
+          if (g.epi == UWU_EPI_NONE) return launch_r3<TC, UWU_EPI_NONE, false, 8>(g, st);
+          if (g.epi == UWU_EPI_BIAS) return launch_r3<TC, UWU_EPI_BIAS, false, 8>(g, st);
+          if (g.epi == UWU_EPI_BIAS_GELU) return launch_r3<TC, UWU_EPI_BIAS_GELU, false, 8>(g, st);
         }
-        return launch_r3<TC>(g, st);
+        return launch_r3<TC, -1, false, 8>(g, st);
       }
     }
     if (g.K % GT<T>::BK == 0 && !no_glds()) {
@@ -1023,6 +1077,11 @@ int dispatch_trans(const GemmArgs& g, int ta, int tb, bool acc, int split, hipSt
   }
   if (ta == 0 && tb == 1) {
     if constexpr (hot) {
+      const int r3 = pick_r3(g, true);
+      if (r3 == 8 && g.epi == UWU_EPI_NONE) return launch_r3<TC, UWU_EPI_NONE, true, 8>(g, st);
+      if (r3 == 8 && g.epi == UWU_EPI_DGELU) return launch_r3<TC, UWU_EPI_DGELU, true, 8>(g, st);
+      if (r3 == 4 && g.epi == UWU_EPI_NONE) return launch_r3<TC, UWU_EPI_NONE, true, 4>(g, st);
+      if (r3 == 4 && g.epi == UWU_EPI_DGELU) return launch_r3<TC, UWU_EPI_DGELU, true, 4>(g, st);
       if (g.epi == UWU_EPI_NONE) return launch<T, TC, false, true, false, false, UWU_EPI_NONE>(g, split, st);
       if (g.epi == UWU_EPI_DGELU) return launch<T, TC, false, true, false, false, UWU_EPI_DGELU>(g, split, st);
     }
