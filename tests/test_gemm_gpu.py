@@ -119,7 +119,7 @@ def test_gemm_rejects_bad_shapes():
         ops.gemm(a, b)
 
 
-# ---- ring kernel (gemm_r3_kernel): picked by the host for K-contiguous bf16 operands once there are >= 1024 tiles of
+# ---- ring kernel (gemm_r3_kernel): picked by the host for K-contiguous bf16 operands once there are >= 512 tiles of
 # 256x128.  It issues the same sequence of 16x16x32 MFMAs per output as the 128x128 kernel, so the two must agree bit
 # for bit on any operands; UWU_GEMM_R3=0 (read per call) keeps a call on the 128x128 kernel, which the tests above
 # pin to the CPU fp64 matmul.

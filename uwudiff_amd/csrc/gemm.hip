@@ -1017,10 +1017,17 @@ int pick_r3(const GemmArgs& g, bool tb) {
   if (g.K % 32 || g.K < 96) return 0;
   if ((((uintptr_t)g.A | (uintptr_t)g.B) & 15) || g.lda % 8 || g.ldb % 8) return 0;
   if (tb && (g.N % 8 || g.N < 8)) return 0;
+  static int thr8 = -1, thr4 = -1;  // tile-count thresholds (env overrides for sweeps)
+  if (thr8 < 0) {
+    const char* e8 = getenv("UWU_R3_T8");
+    const char* e4 = getenv("UWU_R3_T4");
+    thr8 = e8 ? atoi(e8) : 512;  // sweep at per-GPU batches 16..256: 512 / 128 never lose
+    thr4 = e4 ? atoi(e4) : 128;
+  }
   const int64_t t8 = (int64_t)((g.M + 255) / 256) * ((g.N + 127) / 128);
-  if (t8 >= 1024) return 8;
+  if (t8 >= thr8) return 8;
   const int64_t t4 = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128);
-  return (tb && t4 >= 512) ? 4 : 0;  // K-contiguous B at N = 384: gemm_kernel's 128-byte rows measured faster (proj 35 vs 43 us)
+  return (tb && t4 >= thr4) ? 4 : 0;  // K-contiguous B at N = 384: gemm_kernel's 128-byte rows measured faster (proj 35 vs 43 us)
 }
 
 bool no_glds() {
