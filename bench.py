@@ -129,7 +129,7 @@ def main():
     loss_fn = DiffusionLoss(EulerDiscreteScheduler.from_pretrained("stabilityai/stable-diffusion-xl-base-1.0",
                                                                    subfolder="scheduler"))
     opt = FusedAdamW(model.parameters(), lr=1e-6, weight_decay=0.01, betas=(0.9, 0.999))
-    sync = FlatGradSync(world)
+    sync = FlatGradSync(world).attach(model)  # N > 1: block gradients are reduced while the backward still runs
     pool_n = max(4096, 2 * B)
     pool = torch.randn(pool_n, 4, 32, 32, device=dev)          # synthetic latents resident in HBM
     pooled = torch.randn(pool_n, 1280, device=dev)             # synthetic pooled-text conditioning

@@ -264,6 +264,10 @@ typedef struct uwu_dit_desc {
   const float* pos;     /* [T, D] fp32 */
   void* ws;             /* activation workspace (saved for backward) */
   size_t ws_bytes;
+  void* const* layer_done; /* optional: L hipEvent_t handles (or NULL).  uwu_dit_backward records layer_done[l] on its
+                              stream once every parameter-gradient launch of block l has been issued, so a data-parallel
+                              host can start reducing that block's slice of g32 while the backward continues
+                              (blocks finish in the order L-1 .. 0; the non-block parameters finish last). */
 } uwu_dit_desc;
 
 size_t uwu_dit_workspace_bytes(const uwu_dit_desc* d);

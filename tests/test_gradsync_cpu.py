@@ -35,6 +35,16 @@ def _worker(rank, world, port, q):
     dist.all_gather(gathered, mine)
     ref = torch.stack(gathered).sum(0)
     ok = torch.allclose(g, ref, rtol=0, atol=1e-6) and abs(sync.pre_scale - 1.0 / world) < 1e-12
+    # slices reduced early (what DiT.set_grad_ready_hook reports from inside backward) are not reduced twice, and the
+    # returned chunks cover the buffer exactly once
+    g2 = mine.clone()
+    sync2 = FlatGradSync(world, chunk_elems=30_000)
+    sync2._on_ready(g2, [(70_000, 20_003, None), (40_000, 30_000, None)])
+    chunks2 = sync2.all_reduce(g2)
+    cover = sorted(chunks2)
+    ok = ok and torch.allclose(g2, ref, rtol=0, atol=1e-6)
+    ok = ok and cover[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(cover, cover[1:])) and sum(c[1] for c in cover) == n
+    ok = ok and chunks2[:2] == [(40_000, 30_000), (70_000, 20_003)] and sync2._early == []
     lo, hi = shard_range(50, rank, world)
     t = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -1,0 +1,95 @@
+"""GPU, 2 ranks (gloo, both on cuda:0): the gradient exchange overlapped with the backward pass
+(uwu_dit_desc.layer_done events -> DiT.set_grad_ready_hook -> FlatGradSync.attach) gives exactly the gradients of the
+plain exchange after the backward, and an AdamW step from them gives identical parameters on both ranks."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from uwudiff_amd.dit import DiT
+    from uwudiff_amd.gradsync import FlatGradSync
+    from uwudiff_amd.optim import FusedAdamW
+
+    torch.cuda.set_device(0)
+    torch.manual_seed(7)  # identical replicas
+    model = DiT(hidden=128, depth=6, heads=2, patch=2, sample_size=16, in_channels=4, out_channels=4, cond_dim=32,
+                init="random", compute_dtype="bf16").cuda()
+    torch.manual_seed(100 + rank)  # per-rank data
+    B = 8
+    x = torch.randn(B, 4, 16, 16, device="cuda")
+    t = torch.rand(B, device="cuda") * 999
+    c = torch.randn(B, 32, device="cuda")
+    w = torch.randn(B, 4, 16, 16, device="cuda")
+
+    def grads(sync):
+        model.flat.grad = torch.zeros_like(model.flat.data)
+        out = model(x, t, added_cond_kwargs={"text_embeds": c})[0]
+        (out * w).sum().backward()
+        chunks = sync.all_reduce(model.flat.grad)
+        sync.wait_all()
+        torch.cuda.synchronize()
+        return model.flat.grad.clone(), chunks
+
+    plain, chunks_plain = grads(FlatGradSync(world, chunk_elems=200_000))
+    sync = FlatGradSync(world, chunk_elems=200_000).attach(model)
+    assert model._grad_groups is not None and len(model._grad_groups) == 2  # 6 blocks in groups of 4
+    over, chunks = grads(sync)
+    over2, _ = grads(sync)  # events are reused step after step
+    n = model.flat.numel()
+    cover = sorted(chunks)
+    # (split-K atomics make the gradient bits run-to-run dependent, so "same" is a tight tolerance, not torch.equal)
+    tol = 1e-5 * float(plain.abs().max())
+    fails = []
+    if float((plain - over).abs().max()) > tol or float((plain - over2).abs().max()) > tol:
+        fails.append(("grads", float((plain - over).abs().max()), float((plain - over2).abs().max()), tol))
+    if not (cover[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(cover, cover[1:])) and sum(k[1] for k in cover) == n):
+        fails.append(("cover", cover))
+    if [k for k in chunks[:2]] != [(o, l) for o, l, _ in sorted(model._grad_groups)]:
+        fails.append(("early chunks first", chunks[:3], model._grad_groups))
+    ok = not fails
+    # one optimizer step on the chunk list -> identical replicas
+    opt = FusedAdamW(model.parameters(), lr=1e-3, weight_decay=0.01)
+    opt.step(pre_scale=sync.pre_scale, chunks=chunks, before_chunk=sync.wait_chunk)
+    torch.cuda.synchronize()
+    mine = model.flat.data.clone()
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    if not torch.equal(gathered[0], gathered[1]):
+        fails.append(("replicas differ", float((gathered[0] - gathered[1]).abs().max())))
+    model.set_grad_ready_hook(None)
+    q.put((rank, not fails, float(plain.abs().sum()), fails))
+    dist.destroy_process_group()
+
+
+def test_overlapped_exchange_equals_plain_exchange():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
+    assert res[0][2] == res[1][2] and res[0][2] > 0  # the reduced gradient is the same (non-trivial) sum on both ranks

@@ -380,6 +380,12 @@ extern "C" int uwu_dit_backward(const uwu_dit_desc* dp, const float* dout, void*
                           P.lay<float>(l, L.o_lse), P.at<float>(L.delta), dqkv, dqkv + (size_t)D * es,
                           dqkv + (size_t)2 * D * es, B, T, T, d.H, D / d.H, D3, D3, D3, D, scale, dt, st));
     RUN(lin_wgrad(dqkv, P.lay(l, L.o_h1), g + w.off_qkv_w, M, D3, D, dt, st, P.at(L.wsc), L.wsc_bytes, g + w.off_qkv_b));
+    // every parameter gradient of block l is now in flight on `st`
+    if (d.layer_done && d.layer_done[l] &&
+        hipEventRecord(static_cast<hipEvent_t>(d.layer_done[l]), static_cast<hipStream_t>(st)) != hipSuccess) {
+      uwu_set_error("dit_backward: hipEventRecord(layer_done[%d]) failed", l);
+      return UWU_ELAUNCH;
+    }
     RUN(lin_dgrad(dqkv, w.qkv_w, P.at(L.dh), nullptr, M, D3, D, dt, st));
     // LN1 bwd (+ residual) and gate bwd of the previous layer's MLP branch
     if (l > 0) {

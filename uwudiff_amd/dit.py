@@ -118,6 +118,10 @@ class DiT(nn.Module):
         self.register_buffer("shadow", torch.zeros(0, dtype=torch.bfloat16), persistent=False)
         self._ws = None
         self._ws_key = None
+        self._layer_done = None
+        self._layer_events = None
+        self._grad_hook = None
+        self._grad_groups = None
         self._fwd_gen = 0
         self._desc = None
         self.config = type("cfg", (), dict(in_channels=c.in_channels, sample_size=c.sample_size))()
@@ -236,7 +240,42 @@ class DiT(nn.Module):
             self._ws = torch.empty(need, device=self.flat.device, dtype=torch.uint8)
             self._ws_key = key
         d.ws, d.ws_bytes = self._ws.data_ptr(), self._ws.numel()
+        d.layer_done = ctypes.addressof(self._layer_done) if self._layer_done is not None else None
         return d
+
+    # ------------------------------------------------------------------ data-parallel hook
+    def set_grad_ready_hook(self, hook, group_layers=4):
+        """``hook(flat_grad, [(offset, length, event), ...])`` is called inside backward, right after the C++ driver has
+        enqueued the whole pass: each entry is a contiguous slice of ``flat.grad`` (a group of transformer blocks,
+        last group first) and the ``torch.cuda.Event`` the driver records once every gradient launch of that group is
+        in flight (``uwu_dit_desc.layer_done``).  A data-parallel host reduces those slices on its communication
+        stream while the rest of the backward still runs (uwudiff_amd/gradsync.py).  ``hook=None`` switches it off."""
+        self._grad_hook = hook
+        self._grad_groups = None
+        if hook is None:
+            self._layer_done = None
+            self._layer_events = None
+            return
+        if not self.flat.is_cuda:
+            raise L.UwuError("set_grad_ready_hook: move the module to the HIP device first")
+        depth = self.cfg.depth
+        self._layer_events = []
+        with torch.cuda.device(self.flat.device):
+            for _ in range(depth):
+                ev = torch.cuda.Event()
+                ev.record()  # materialises the hipEvent_t behind the torch object
+                self._layer_events.append(ev)
+        self._layer_done = (ctypes.c_void_p * depth)(*[ev.cuda_event for ev in self._layer_events])
+        off0 = self.registry["blocks.0.qkv.weight"][0]
+        stride = L.load().uwu_dit_layer_param_stride(self.cfg.hidden, self.cfg.mlp_ratio)
+        groups = []
+        hi = depth
+        while hi > 0:  # blocks finish in the order depth-1 .. 0: the lowest block of a group is its last
+            lo = max(0, hi - group_layers)
+            groups.append((off0 + lo * stride, (hi - lo) * stride, self._layer_events[lo]))
+            hi = lo
+        assert off0 + depth * stride == self.n_flat, "transformer blocks must be the tail of the flat buffer"
+        self._grad_groups = groups
 
     def _run_forward(self, noisy, t, cond):
         B = noisy.shape[0]
@@ -252,6 +291,8 @@ class DiT(nn.Module):
             self.flat.grad = torch.zeros_like(self.flat.data)
         d = self._descriptor(dout.shape[0])
         L.call("uwu_dit_backward", ctypes.byref(d), L.ptr(dout), L.stream())
+        if self._grad_hook is not None:
+            self._grad_hook(self.flat.grad, self._grad_groups)
         if cond is not None:
             L.call("uwu_dit_backward_cond", ctypes.byref(d), L.ptr(cond), L.stream())
 

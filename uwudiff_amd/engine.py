@@ -113,7 +113,7 @@ class Fitter:
         cfg = module.configure_optimizers()
         opt = cfg["optimizer"] if isinstance(cfg, dict) else cfg
         sched = cfg["lr_scheduler"]["scheduler"] if isinstance(cfg, dict) and "lr_scheduler" in cfg else None
-        sync = FlatGradSync(self.world_size)
+        sync = FlatGradSync(self.world_size).attach(module.unet)
         params = [p for g in opt.param_groups for p in g["params"]]
         max_steps = 1 if self.fast_dev_run else self.max_steps
         t0 = time.time()

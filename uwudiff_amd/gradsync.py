@@ -11,6 +11,12 @@ kernel for chunk i waits only on event i, so AdamW on already-reduced chunks ove
 rest (the mesh is point-to-point: 7 links x ~153 GB/s per GPU, so chunks are sized in the tens of MB, not the
 25 MB DDP bucket default).  With gradient clipping the global norm needs every chunk first, so the optimizer
 waits on the last event.  On CPU tensors (gloo, used by the tests) the same code runs synchronously.
+
+Overlap with the backward pass: a model that can tell when a slice of its flat gradient is final (the DiT driver
+records one event per group of transformer blocks, ``DiT.set_grad_ready_hook``) is attached with :meth:`attach`;
+those slices (2/3 of DiT-S/2's gradient bytes) are reduced on the communication stream behind their event while the
+rest of the backward still runs, and :meth:`all_reduce` afterwards only reduces what is left.  Every rank issues the
+same collectives in the same order (block groups last-to-first, then the remainder in offset order).
 """
 import torch
 import torch.distributed as dist
@@ -23,6 +29,7 @@ class FlatGradSync:
         self.chunk_elems = int(chunk_elems)
         self._comm_stream = None
         self.events = []
+        self._early = []  # [(offset, length, event)] reduced from inside the backward of the current step
 
     @property
     def pre_scale(self):
@@ -32,28 +39,73 @@ class FlatGradSync:
         c = self.chunk_elems
         return [(o, min(c, n - o)) for o in range(0, n, c)]
 
+    def _stream(self, device):
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=device)
+        return self._comm_stream
+
+    def attach(self, model):
+        """Reduce the slices ``model`` reports as final from inside its backward (no-op for one rank or for models
+        without ``set_grad_ready_hook``).  Call once, after the model is on its device."""
+        if self.world > 1 and hasattr(model, "set_grad_ready_hook"):
+            model.set_grad_ready_hook(self._on_ready)
+        return self
+
+    def _on_ready(self, flat_grad, ranges):
+        """Called by the model between enqueueing its backward launches and returning to autograd."""
+        if self.world == 1:
+            return
+        if not flat_grad.is_cuda:  # gloo on CPU tensors (tests): synchronous
+            for off, ln, _ in ranges:
+                dist.all_reduce(flat_grad[off:off + ln], op=dist.ReduceOp.SUM, group=self.group)
+                self._early.append((off, ln, None))
+            return
+        comm = self._stream(flat_grad.device)
+        with torch.cuda.stream(comm):
+            for off, ln, ready in ranges:
+                comm.wait_event(ready)  # every gradient launch of this slice has completed
+                dist.all_reduce(flat_grad[off:off + ln], op=dist.ReduceOp.SUM, group=self.group)
+                ev = torch.cuda.Event()
+                ev.record(comm)
+                self._early.append((off, ln, ev))
+
     def all_reduce(self, flat_grad: torch.Tensor):
-        """Launch the (chunked) sum-all-reduce of ``flat_grad`` in place.  Returns the chunk list; on CUDA the
-        work is asynchronous on the communication stream and ``self.events[i]`` marks chunk i reduced."""
+        """Launch the (chunked) sum-all-reduce of ``flat_grad`` in place -- of whatever :meth:`_on_ready` has not
+        reduced already during this step's backward.  Returns the chunk list [(offset, length), ...] covering the whole
+        buffer; on CUDA the work is asynchronous on the communication stream and ``self.events[i]`` marks chunk i
+        reduced."""
         n = flat_grad.numel()
-        chunks = self.chunks(n)
+        early, self._early = sorted(self._early), []
         self.events = []
         if self.world == 1:
-            return chunks
+            return self.chunks(n)
+        # the remainder: gaps between the early slices, cut into chunk_elems pieces
+        rest, pos = [], 0
+        for off, ln, _ in early + [(n, 0, None)]:
+            while pos < off:
+                step = min(self.chunk_elems, off - pos)
+                rest.append((pos, step))
+                pos += step
+            pos = max(pos, off + ln)
+        chunks = []
         if flat_grad.is_cuda:
-            if self._comm_stream is None:
-                self._comm_stream = torch.cuda.Stream(device=flat_grad.device)
-            cur = torch.cuda.current_stream(flat_grad.device)
-            self._comm_stream.wait_stream(cur)  # backward finished producing the buffer
-            with torch.cuda.stream(self._comm_stream):
-                for off, ln in chunks:
+            comm = self._stream(flat_grad.device)
+            comm.wait_stream(torch.cuda.current_stream(flat_grad.device))  # backward finished producing the buffer
+            for off, ln, ev in early:  # already reduced (or about to be): the optimizer starts with these
+                chunks.append((off, ln))
+                self.events.append(ev)
+            with torch.cuda.stream(comm):
+                for off, ln in rest:
                     dist.all_reduce(flat_grad[off:off + ln], op=dist.ReduceOp.SUM, group=self.group)
                     ev = torch.cuda.Event()
-                    ev.record(self._comm_stream)
+                    ev.record(comm)
+                    chunks.append((off, ln))
                     self.events.append(ev)
         else:
-            for off, ln in chunks:
+            chunks += [(off, ln) for off, ln, _ in early]
+            for off, ln in rest:
                 dist.all_reduce(flat_grad[off:off + ln], op=dist.ReduceOp.SUM, group=self.group)
+                chunks.append((off, ln))
         return chunks
 
     def wait_chunk(self, i):
@@ -61,8 +113,8 @@ class FlatGradSync:
             torch.cuda.current_stream().wait_event(self.events[i])
 
     def wait_all(self):
-        if self.events:
-            torch.cuda.current_stream().wait_event(self.events[-1])
+        for ev in self.events:
+            torch.cuda.current_stream().wait_event(ev)
 
 
 def shard_range(n_items, rank, world):

@@ -30,7 +30,7 @@ class DitDesc(ctypes.Structure):
         + [(n, c_int64) for n in ("off_patch_w", "off_patch_b", "off_t_w1", "off_t_b1", "off_t_w2", "off_t_b2",
                                   "off_y_w", "off_y_b", "off_mod_w", "off_mod_b", "off_final_w", "off_final_b",
                                   "off_layer0", "layer_stride")]
-        + [("pos", c_void_p), ("ws", c_void_p), ("ws_bytes", c_size_t)]
+        + [("pos", c_void_p), ("ws", c_void_p), ("ws_bytes", c_size_t), ("layer_done", c_void_p)]
     )
 
 
