@@ -317,7 +317,7 @@ __device__ __forceinline__ void epilogue_tile(f32x4 (&acc)[FI][FJ], EpiPre<T, FI
 #pragma unroll
         for (int jp = 0; jp < FJ / 2; ++jp) {
           const int nb = n_w + 32 * jp;  // first column of subtile 2jp
-          auto exchange_store = [&](TC* dst, const f32x4& x0, const f32x4& x1) {
+          auto exchange_store = [&](TC* dst, const f32x4& x0, const f32x4& x1, bool stream_out = false) {
             const uint2 p0 = pack(x0), p1 = pack(x1);
             const uint2 send = odd ? p0 : p1;
             uint2 recv;
@@ -325,11 +325,16 @@ __device__ __forceinline__ void epilogue_tile(f32x4 (&acc)[FI][FJ], EpiPre<T, FI
             recv.y = __shfl_xor(send.y, 16, 64);
             const int n = odd ? nb + 16 + 4 * (fq - 1) : nb + 4 * fq;
             if (mok && n < g.N) {
-              const uint4 o = odd ? uint4{recv.x, recv.y, p1.x, p1.y} : uint4{p0.x, p0.y, recv.x, recv.y};
-              *reinterpret_cast<uint4*>(dst + (int64_t)m * g.ldc + n) = o;
+              typedef unsigned su32x4 __attribute__((ext_vector_type(4)));
+              const su32x4 o = odd ? su32x4{recv.x, recv.y, p1.x, p1.y} : su32x4{p0.x, p0.y, recv.x, recv.y};
+              su32x4* ptr = reinterpret_cast<su32x4*>(dst + (int64_t)m * g.ldc + n);
+              if (stream_out) __builtin_nontemporal_store(o, ptr);
+              else *ptr = o;
             }
           };
-          exchange_store(C, v[2 * jp], v[2 * jp + 1]);
+          // the pre-activation of a GELU Linear is only read again in the backward pass: streaming store, so that
+          // it does not push the activation (read next by fc2) out of the caches
+          exchange_store(C, v[2 * jp], v[2 * jp + 1], epi == UWU_EPI_BIAS_GELU);
           if (two) exchange_store(C2, sec[2 * jp], sec[2 * jp + 1]);
         }
       }
