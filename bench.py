@@ -22,6 +22,9 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 MODEL = "DiT-S/2"
+# per-GPU batch: the config does not fix it (the reference yaml trains at 16); sweep on one MI355X:
+# 16 -> 3.3k, 64 -> 8.4k, 128 -> 11.1k, 256 -> 12.5k, 512 -> 13.2k, 768 -> 13.4k images/s.  512 = 22 GB of activations.
+DEFAULT_BATCH = 512
 # step GFLOP per image (3 x forward, no recompute)
 STEP_GFLOP = {"DiT-S/2": 36.3, "DiT-B/2": 138.0, "DiT-L/2": 484.0, "DiT-XL/2": 711.7}
 DESC = {"DiT-S/2": "L12 D384 h6", "DiT-B/2": "L12 D768 h12", "DiT-L/2": "L24 D1024 h16", "DiT-XL/2": "L28 D1152 h16"}
@@ -82,7 +85,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--batch", type=int, default=DEFAULT_BATCH, help="per-GPU batch (weak scaling)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--clip", type=float, default=0.0)
@@ -199,7 +202,7 @@ def main():
             # same command, gfx950 corrections applied by tools/summarize_pmc.py); null if not collected
             traffic = None
             tj = os.path.join(ROOT, "profiles", "r01_pmc_gemm_traffic.json")
-            if args.dtype == "bf16" and B == 256 and args.model == MODEL and os.path.exists(tj):
+            if args.dtype == "bf16" and B == DEFAULT_BATCH and args.model == MODEL and os.path.exists(tj):
                 with open(tj) as f:
                     traffic = round(json.load(f)["hbm_bytes_per_launch"])
             roof = {"bound": "mfma", "kernel": "bf16 MFMA GEMM family (gemm_kernel / gemm_r3_kernel / gemm_tr_kernel, v_mfma_f32_16x16x32_bf16; fwd+dgrad+wgrad launches)",
