@@ -196,30 +196,6 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_mfma(const MArgs a) {
   }
 }
 
-// delta[b,h,t] = sum_d dO*O ; 8 lanes per head (16 B each), one wave covers 8 heads of one row
-__global__ void __launch_bounds__(256) attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dO,
-                                                         float* __restrict__ delta, int B, int T, int H, int ldo) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t rows = (int64_t)B * T;
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
-    const int b = (int)(row / T), t = (int)(row - (int64_t)b * T);
-    for (int h0 = 0; h0 < H; h0 += 8) {
-      const int hd = h0 + (lane >> 3);
-      float s = 0.f;
-      if (hd < H) {
-        const int64_t off = row * ldo + hd * 64 + 8 * (lane & 7);
-        bf16x8 ov = *reinterpret_cast<const bf16x8*>(o + off), gv = *reinterpret_cast<const bf16x8*>(dO + off);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s += (float)ov[j] * (float)gv[j];
-      }
-      s += __shfl_xor(s, 1, 64);
-      s += __shfl_xor(s, 2, 64);
-      s += __shfl_xor(s, 4, 64);
-      if (hd < H && (lane & 7) == 0) delta[((int64_t)b * H + hd) * T + t] = s;
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------- backward
 constexpr int BWD_STAGE = 32768;                    // Qs | dOs | QTs | dOTs (8 KB each)
 constexpr int BWD_OFF_LSE = 2 * BWD_STAGE;          // [2][64] lse*log2e, [2][64] delta
@@ -242,8 +218,8 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
   const bf16_t* kb = a.k + (int64_t)b * a.T * a.ldk + hd * 64;
   const bf16_t* vb = a.v + (int64_t)b * a.T * a.ldv + hd * 64;
   const bf16_t* gb = a.dO + (int64_t)b * a.T * a.ldo + hd * 64;
+  const bf16_t* ob = a.o + (int64_t)b * a.T * a.ldo + hd * 64;
   const float* lseb = a.lse + ((int64_t)b * a.H + hd) * a.T;
-  const float* delb = a.delta + ((int64_t)b * a.H + hd) * a.T;
   const float c = a.scale * 1.4426950408889634f;
   char* dsimg = smem + BWD_OFF_DS;
   char* ktimg = smem + BWD_OFF_KT;
@@ -283,16 +259,18 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
   dkT[0] = dkT[1] = dvT[0] = dvT[1] = f32x16{};
 
   // staging registers: row-major Q and dO (one 16-B chunk each), transposed Q (threads 0-255) or dO (256-511)
-  uint4 qreg, greg;
+  // delta[q] = sum_d dO[q][d] * O[q][d] is computed here from the staged dO chunk and the matching O chunk (8 lanes
+  // per row, three shuffles) instead of by a separate pass over O and dO
+  uint4 qreg, greg, oreg;
   TStage treg;
-  float lreg = 0.f, dreg = 0.f;
+  float lreg = 0.f;
   auto load_tile = [&](int q0) {
     const int row = tid >> 3, ch = tid & 7;
     qreg = *reinterpret_cast<const uint4*>(qb + (int64_t)(q0 + row) * a.ldq + 8 * ch);
     greg = *reinterpret_cast<const uint4*>(gb + (int64_t)(q0 + row) * a.ldo + 8 * ch);
+    oreg = *reinterpret_cast<const uint4*>(ob + (int64_t)(q0 + row) * a.ldo + 8 * ch);
     if (tid < 256) treg.load(qb, a.ldq, q0, tid); else treg.load(gb, a.ldo, q0, tid - 256);
     if (tid < 64) lreg = lseb[q0 + tid] * 1.4426950408889634f;
-    else if (tid < 128) dreg = delb[q0 + tid - 64];
   };
   auto store_tile = [&](int stage) {
     char* st = smem + stage * BWD_STAGE;
@@ -303,7 +281,14 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
     float* ls = reinterpret_cast<float*>(smem + BWD_OFF_LSE) + stage * 64;
     float* dl = reinterpret_cast<float*>(smem + BWD_OFF_LSE + 512) + stage * 64;
     if (tid < 64) ls[tid] = lreg;
-    else if (tid < 128) dl[tid - 64] = dreg;
+    const bf16x8 gv = *reinterpret_cast<const bf16x8*>(&greg), ov = *reinterpret_cast<const bf16x8*>(&oreg);
+    float ds = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ds += (float)gv[j] * (float)ov[j];
+    ds += __shfl_xor(ds, 1, 64);
+    ds += __shfl_xor(ds, 2, 64);
+    ds += __shfl_xor(ds, 4, 64);
+    if (ch == 0) dl[row] = ds;
   };
 
   const int nt = a.T / 64;
@@ -439,11 +424,7 @@ int uwu_attn_mfma_bwd(const void* q, const void* k, const void* v, const void* o
                               BWD_LDS);
     attr_done = true;
   }
-  int grid = (int)(((int64_t)B * T + 3) / 4);
-  if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)o, (const bf16_t*)dO, delta, B, T,
-                     H, ldo);
-  UWU_LAUNCH_CHECK("attention_delta");
+  (void)delta;  // the row sums of dO * O are formed inside the kernel
   MArgs a{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o;
   a.dO = (const bf16_t*)dO; a.lse = const_cast<float*>(lse); a.delta = delta;
