@@ -97,6 +97,13 @@ int uwu_scale_inplace(void* y, int dtype, int64_t n, const float* scale, void* s
 int uwu_sampler_step(const float* x, const float* eps_cond, const float* eps_uncond, const float* noise, float* out,
                      float* denoised, int64_t n, float cfg, float sigma, float sigma_down, float sigma_up,
                      float s_noise, void* stream);
+/* General sampler update for the DPM-Solver-2 and CFG++ variants (sampling/k_diffusion_dpm2.py:8-111,
+ * k_diffusion_euler.py:51-106): every step of those samplers is
+ *   out = base + a * eps_cfg + b * eps_uncond + c * noise,   eps_cfg = eps_uncond + (eps_cond - eps_uncond) * cfg
+ * for scalars (a, b, c) derived from the sigmas on the host (denoised = x - sigma eps; to_d(x, sigma, denoised) = eps).
+ * eps_uncond NULL: unguided (eps_uncond := eps_cond).  noise NULL: no noise term. */
+int uwu_sampler_combine(const float* base, const float* eps_cond, const float* eps_uncond, const float* noise,
+                        float* out, int64_t n, float cfg, float a, float b, float c, void* stream);
 int uwu_scale_copy(const float* x, float* y, int64_t n, float scale, void* stream);
 
 /* ------------------------------------------------------------------ optimizer (a15) */

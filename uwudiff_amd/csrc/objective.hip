@@ -317,6 +317,29 @@ extern "C" int uwu_sampler_step(const float* x, const float* eps_cond, const flo
   return UWU_OK;
 }
 
+// out = base + a * (eu + cfg (ec - eu)) + b * eu + c * noise ; eu == NULL: unguided (eu := ec); noise == NULL: c unused
+__global__ void __launch_bounds__(256) sampler_combine_kernel(const float* __restrict__ base, const float* __restrict__ ec,
+                                                              const float* __restrict__ eu, const float* __restrict__ nz,
+                                                              float* __restrict__ out, int64_t n4, float cfg, float a,
+                                                              float b, float c) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const f32x4 xv = load4(base + 4 * i), cv = load4(ec + 4 * i);
+    const f32x4 uv = eu ? load4(eu + 4 * i) : cv;
+    f32x4 o = xv + (uv + (cv - uv) * cfg) * a + uv * b;
+    if (nz) o = o + load4(nz + 4 * i) * c;
+    store4(out + 4 * i, o);
+  }
+}
+
+extern "C" int uwu_sampler_combine(const float* base, const float* eps_cond, const float* eps_uncond, const float* noise,
+                                   float* out, int64_t n, float cfg, float a, float b, float c, void* stream) {
+  UWU_CHECK_ARG(base && eps_cond && out && n > 0 && n % 4 == 0, "sampler_combine: bad args");
+  hipLaunchKernelGGL(sampler_combine_kernel, dim3(ew_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, base,
+                     eps_cond, eps_uncond, noise, out, n / 4, cfg, a, b, c);
+  UWU_LAUNCH_CHECK("sampler_combine");
+  return UWU_OK;
+}
+
 extern "C" int uwu_scale_copy(const float* x, float* y, int64_t n, float scale, void* stream) {
   UWU_CHECK_ARG(x && y && n > 0 && n % 4 == 0, "scale_copy: bad args");
   hipLaunchKernelGGL(scale_copy_kernel, dim3(ew_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n / 4, scale);

@@ -127,3 +127,102 @@ def sample_euler_ancestral(denoiser: DiscreteEpsDDPMDenoiser, x, sigmas, cond_kw
             callback({"x": x, "i": i, "sigma": sigmas[i], "sigma_hat": sigmas[i], "denoised": den})
         x = out
     return x
+
+
+# ---- DPM-Solver-2 and the CFG++ variants (section 8f rank 1).  Every update of these samplers is
+#   out = base + a * eps_cfg + b * eps_uncond + c * noise      (uwu_sampler_combine)
+# because the wrapped model predicts eps: denoised = x - sigma * eps and k-diffusion's to_d(x, sigma, denoised) = eps.
+def _eval_eps(denoiser, x, xin, sigma, kw, guided):
+    """(eps_cond, eps_uncond | None) of the eps model at (x, sigma): c_in scaling + one batched call for both branches."""
+    L.call("uwu_scale_copy", L.ptr(x), L.ptr(xin), x.numel(), 1.0 / math.sqrt(sigma * sigma + 1.0), L.stream())
+    if guided:
+        eps = denoiser.eps(torch.cat([xin, xin]), sigma, **kw).float().contiguous()
+        return eps[: x.shape[0]], eps[x.shape[0]:]
+    return denoiser.eps(xin, sigma, **kw).float().contiguous(), None
+
+
+def _combine(base, eps_c, eps_u, noise, cfg, a, b, c=0.0):
+    out = torch.empty_like(base)
+    L.call("uwu_sampler_combine", L.ptr(base), L.ptr(eps_c), L.ptr(eps_u) if eps_u is not None else None,
+           L.ptr(noise) if noise is not None else None, L.ptr(out), base.numel(), float(cfg), float(a), float(b),
+           float(c), L.stream())
+    return out
+
+
+def sample_euler_ancestral_cfgpp(denoiser: DiscreteEpsDDPMDenoiser, x, sigmas, cond_kwargs, uncond_kwargs, cfg=1.0, eta=1.0,
+                                 s_noise=1.0, noise_sampler=None):
+    """k_diffusion_euler.py:51-106 (image_to_noise=False): x' = cfg_denoised + to_d(x, sigma, uncond_denoised) * sigma_down
+    (+ noise) = x - sigma eps_cfg + sigma_down eps_uncond (+ s_noise sigma_up noise)."""
+    x = x.float().contiguous()
+    kw = _cat_kwargs(cond_kwargs, uncond_kwargs)
+    xin = torch.empty_like(x)
+    for i in range(len(sigmas) - 1):
+        s, s_next = float(sigmas[i]), float(sigmas[i + 1])
+        eps_c, eps_u = _eval_eps(denoiser, x, xin, s, kw, True)
+        sd, su = get_ancestral_step(s, s_next, eta)
+        noise = None
+        if s_next > 0:
+            noise = (noise_sampler(i) if noise_sampler is not None else torch.randn_like(x)).float().contiguous()
+        x = _combine(x, eps_c, eps_u, noise, cfg, -s, sd, s_noise * su)
+    return x
+
+
+def sample_dpm2(denoiser: DiscreteEpsDDPMDenoiser, x, sigmas, cond_kwargs, uncond_kwargs=None, cfg=1.0, s_churn=0.0,
+                s_tmin=0.0, s_tmax=float("inf"), s_noise=1.0, single_call=False, noise_sampler=None):
+    """k_diffusion_dpm2.py:8-57.  ``single_call`` reuses the midpoint derivative of the previous step as this step's
+    first derivative (one model call per step), as the reference does."""
+    x = x.float().contiguous()
+    guided = uncond_kwargs is not None
+    kw = _cat_kwargs(cond_kwargs, uncond_kwargs) if guided else cond_kwargs
+    xin = torch.empty_like(x)
+    cached = None
+    nsteps = len(sigmas) - 1
+    for i in range(nsteps):
+        s, s_next = float(sigmas[i]), float(sigmas[i + 1])
+        gamma = min(s_churn / nsteps, 2 ** 0.5 - 1) if s_tmin <= s <= s_tmax else 0.0
+        s_hat = s * (gamma + 1)
+        if gamma > 0:
+            noise = (noise_sampler(i) if noise_sampler is not None else torch.randn_like(x)).float().contiguous()
+            zero = torch.zeros_like(x)
+            x = _combine(x, zero, None, noise, 1.0, 0.0, 0.0, s_noise * (s_hat ** 2 - s ** 2) ** 0.5)
+        if s_next == 0:  # Euler step
+            eps_c, eps_u = _eval_eps(denoiser, x, xin, s_hat, kw, guided)
+            x = _combine(x, eps_c, eps_u, None, cfg, s_next - s_hat, 0.0)
+            continue
+        if single_call and cached is not None:
+            eps_c, eps_u = cached
+        else:
+            eps_c, eps_u = _eval_eps(denoiser, x, xin, s_hat, kw, guided)
+        s_mid = math.exp(0.5 * (math.log(s_hat) + math.log(s_next)))
+        x2 = _combine(x, eps_c, eps_u, None, cfg, s_mid - s_hat, 0.0)
+        eps_c2, eps_u2 = _eval_eps(denoiser, x2, xin, s_mid, kw, guided)
+        cached = (eps_c2, eps_u2)
+        x = _combine(x, eps_c2, eps_u2, None, cfg, s_next - s_hat, 0.0)
+    return x
+
+
+def sample_dpm2_cfgpp(denoiser: DiscreteEpsDDPMDenoiser, x, sigmas, cond_kwargs, uncond_kwargs, cfg=1.0, s_churn=0.0,
+                      s_tmin=0.0, s_tmax=float("inf"), s_noise=1.0, noise_sampler=None):
+    """k_diffusion_dpm2.py:60-111 (single_call=False; the reference marks cfg++ with single_call as not working):
+    x_2 = cfg_denoised + uncond_d * sigma_mid;  x' = cfg_denoised_2 + uncond_d_2 * sigma_next;  last step x' = cfg_denoised."""
+    x = x.float().contiguous()
+    kw = _cat_kwargs(cond_kwargs, uncond_kwargs)
+    xin = torch.empty_like(x)
+    nsteps = len(sigmas) - 1
+    for i in range(nsteps):
+        s, s_next = float(sigmas[i]), float(sigmas[i + 1])
+        gamma = min(s_churn / nsteps, 2 ** 0.5 - 1) if s_tmin <= s <= s_tmax else 0.0
+        s_hat = s * (gamma + 1)
+        if gamma > 0:
+            noise = (noise_sampler(i) if noise_sampler is not None else torch.randn_like(x)).float().contiguous()
+            zero = torch.zeros_like(x)
+            x = _combine(x, zero, None, noise, 1.0, 0.0, 0.0, s_noise * (s_hat ** 2 - s ** 2) ** 0.5)
+        eps_c, eps_u = _eval_eps(denoiser, x, xin, s_hat, kw, True)
+        if s_next == 0:
+            x = _combine(x, eps_c, eps_u, None, cfg, -s_hat, 0.0)  # x = cfg_denoised
+            continue
+        s_mid = math.exp(0.5 * (math.log(s_hat) + math.log(s_next)))
+        x2 = _combine(x, eps_c, eps_u, None, cfg, -s_hat, s_mid)
+        eps_c2, eps_u2 = _eval_eps(denoiser, x2, xin, s_mid, kw, True)
+        x = _combine(x2, eps_c2, eps_u2, None, cfg, -s_mid, s_next)
+    return x
