@@ -89,6 +89,19 @@ int uwu_loss_fwd_bwd(const float* x, const float* noise, const float* xt, const 
 /* y[i] *= *scale (device scalar); used when autograd hands a non-unit upstream gradient. */
 int uwu_scale_inplace(void* y, int dtype, int64_t n, const float* scale, void* stream);
 
+/* Conditioning front-end (section 8f rank 4): ragged -> padded aggregation of per-caption embeddings.
+ * Reference src/duwu/utils/aggregation.py:6-171.  `starts` = device int32 [B+1] prefix sums of n_elements; one "unit"
+ * is one caption's [seq, ...] block of unit_bytes contiguous bytes (any dtype: pure byte movement).
+ *   concat: out[b, 0 : n_b * unit] = emb[starts[b] : starts[b+1]], the rest of the max_n * unit row = pad pattern
+ *           (pad_bits = the pad value's bit pattern in the low elem_size bytes)       aggregation.py:15-39,64-108
+ *   split:  inverse of concat (gathers the valid prefix of every padded row)           aggregation.py:111-171
+ *   first:  out[b] = emb[starts[b]]                                                    aggregation.py:174-185 */
+int uwu_aggregate_concat(const void* emb, const int* starts, void* out, int B, int max_n, int64_t unit_bytes,
+                         int elem_size, uint64_t pad_bits, void* stream);
+int uwu_aggregate_split(const void* cat, const int* starts, void* out, int B, int max_n, int64_t unit_bytes,
+                        void* stream);
+int uwu_aggregate_first(const void* emb, const int* starts, void* out, int B, int64_t unit_bytes, void* stream);
+
 /* Sampler (section 8f rank 1).  One Euler-ancestral step with classifier-free guidance, fused:
  *   eps = uncond + (cond-uncond)*cfg  (reference sampling/cfg.py:113-125; eps_uncond NULL -> no guidance)
  *   denoised = x - sigma*eps          (sampling/k_diffusion_wrapper.py:98-108)

@@ -201,6 +201,26 @@ def main():
          rf_sigmas_16=np.ascontiguousarray(kd["gs"].get_sigmas_for_rf(16, float(ds.sigma_max))).astype(np.float64),
          rf_sigmas_8_min=np.ascontiguousarray(kd["gs"].get_sigmas_for_rf(8, 14.6146, 0.03)).astype(np.float64))
 
+    # aggregation.py loads by file path (torch only) -- section 8f rank 4
+    spec = importlib.util.spec_from_file_location("_ref_agg", os.path.join(REF, "utils/aggregation.py"))
+    agg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(agg)
+    torch.manual_seed(5)
+    for name, n_el, shape, dtype, pad, pad_to in (("a", [2, 3, 1], (4, 5), torch.float32, 0.0, None),
+                                                  ("b", [1, 4, 2, 3], (3, 5), torch.float32, -1.5, 5),
+                                                  ("c", [3, 1, 2], (7,), torch.int64, 0, 4),
+                                                  ("d", [2, 2, 5, 1, 1], (77, 8), torch.float32, 0.25, None)):
+        tot = sum(n_el)
+        emb = torch.randint(0, 2, (tot, *shape)) if dtype == torch.int64 else torch.randn(tot, *shape)
+        cat = agg.aggregate_embeddings(emb, n_el, "concat", pad_value=pad, pad_to_n_elements=pad_to)
+        cat_loop = agg.concat_aggregate_embeddings(emb, n_el, pad_value=pad, pad_to_n_elements=pad_to)
+        assert torch.equal(cat, cat_loop)
+        rec = agg.split_aggregate_embeddings(cat, n_el, shape[0])
+        assert torch.equal(rec, emb)
+        fst = agg.aggregate_embeddings(emb, n_el, "first")
+        save("aggregation_" + name, dict(kind="aggregation", n_elements=n_el, pad_value=pad, pad_to_n_elements=pad_to,
+                                         seq=shape[0]), emb=emb, cat=cat, first=fst)
+
     # AxialRoPE(64, 4) forward (modules/rope.py:83-108) -- "next" row (f2), importable reference
     rope = load_reference_rope()
     torch.manual_seed(0)

@@ -93,5 +93,21 @@ class ConcatTextEncoders(nn.Module):
     def tokenize(self, text, **kw):
         return [t(text, **kw) for t in self.tokenizers]
 
-    def encode(self, text, **kw):
-        return self.forward(self.tokenize(text, **kw))
+    def encode(self, text, nested: bool = False, pad_to_n_elements=None, **kw):
+        """reference text_encoders.py:102-137.  ``nested``: ``text`` is a list of caption lists (one list per image);
+        the per-caption contexts are concatenated per image on the sequence axis and padded to the longest image
+        (``duwu.utils.aggregation``, HIP kernels), the pooled vector is the first caption's."""
+        if not nested:
+            return self.forward(self.tokenize(text, **kw))
+        from duwu.utils.aggregation import aggregate_embeddings
+
+        n_per_image = [len(t) for t in text]
+        flat = [c for t in text for c in t]
+        embs, normed, pools, masks = self.forward(self.tokenize(flat, **kw))
+        embs = aggregate_embeddings(embs, n_per_image, mode="concat", pad_to_n_elements=pad_to_n_elements)
+        normed = aggregate_embeddings(normed, n_per_image, mode="concat", pad_to_n_elements=pad_to_n_elements)
+        if pools is not None:  # only the first provided caption is used for pooling
+            pools = aggregate_embeddings(pools, n_per_image, mode="first")
+        if masks is not None:
+            masks = aggregate_embeddings(masks, n_per_image, mode="concat", pad_to_n_elements=pad_to_n_elements)
+        return embs, normed, pools, masks

@@ -44,6 +44,9 @@ _SIGS = {
     "uwu_loss_fwd_bwd": (c_int, [P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int64, P, P, P, P, P, P]),
     "uwu_scale_inplace": (c_int, [P, c_int, c_int64, P, P]),
     "uwu_sampler_step": (c_int, [P, P, P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, P]),
+    "uwu_aggregate_concat": (c_int, [P, P, P, c_int, c_int, c_int64, c_int, ctypes.c_uint64, P]),
+    "uwu_aggregate_split": (c_int, [P, P, P, c_int, c_int, c_int64, P]),
+    "uwu_aggregate_first": (c_int, [P, P, P, c_int, c_int64, P]),
     "uwu_sampler_combine": (c_int, [P, P, P, P, P, c_int64, c_float, c_float, c_float, c_float, P]),
     "uwu_scale_copy": (c_int, [P, P, c_int64, c_float, P]),
     "uwu_grad_sqnorm_clip": (c_int, [P, c_int64, c_float, c_float, P, P, P]),
