@@ -1106,11 +1106,6 @@ int dispatch_trans(const GemmArgs& g, int ta, int tb, bool acc, int split, hipSt
 
 }  // namespace
 
-// 4-stage LDS-DMA ring kernel for the K-contiguous case (gemm_ring.hip)
-bool uwu_gemm_ring_ok(int K, int dtype);
-int uwu_gemm_ring(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux, int M, int N,
-                  int K, int lda, int ldb, int ldc, int ldaux, int dtype, int c_dtype, int epilogue, hipStream_t st);
-
 extern "C" int uwu_gemm(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux, int M,
                         int N, int K, int lda, int ldb, int ldc, int ldaux, int transA, int transB, int dtype,
                         int c_dtype, int epilogue, int split_k, void* stream) {
@@ -1142,19 +1137,6 @@ extern "C" int uwu_gemm(const void* A, const void* B, void* C, void* C2, const f
                     "gemm: aux missing/misaligned");
   } else {
     UWU_CHECK_ARG(c_dtype == UWU_F32 && ldc >= N, "gemm: ACCUM needs fp32 C");
-  }
-  if (!transA && !transB && !acc && uwu_gemm_ring_ok(K, dtype)) {
-    const bool rec = g_prof.on && g_prof.n < GemmProf::MAXP;
-    if (rec) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], (hipStream_t)stream);
-    int rc = uwu_gemm_ring(A, B, C, C2, bias, aux, M, N, K, lda, ldb, ldc, ldaux, dtype, c_dtype, epilogue,
-                           (hipStream_t)stream);
-    if (rec) {
-      (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], (hipStream_t)stream);
-      g_prof.flops[g_prof.n] = 2.0 * M * N * K;
-      g_prof.kind[g_prof.n] = dtype == UWU_BF16 ? 0 : 1;
-      ++g_prof.n;
-    }
-    return rc;
   }
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.C2 = C2; g.bias = bias; g.aux = aux;
