@@ -27,3 +27,23 @@ for _ in range(N): l = step()
 torch.cuda.synchronize(); dt = (time.time() - t0) / N
 fl = 1283e9 if S == 32 else 20284e9
 print(f"B={B} S={S}: {dt*1e3:.1f} ms/step, {B/dt:.2f} img/s, {B*fl/dt/1e12:.1f} TFLOP/s, loss {float(l):.4f}, mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
+if os.environ.get("UWU_PROBE_GRAPH", "1") == "1":
+    # the same forward+backward replayed from a hipGraph (torch.cuda.CUDAGraph around the ctypes launches): the python
+    # composition of ~4000 launches per step is host-bound, the replay is not
+    def fwd_bwd():
+        m.flat.grad.zero_()
+        loss, _ = lf(x, m, **kw); loss.backward(); return loss
+    s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2): fwd_bwd()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        sl = fwd_bwd()
+    for _ in range(2):
+        g.replay(); opt.step()
+    torch.cuda.synchronize(); t0 = time.time()
+    for _ in range(N):
+        g.replay(); opt.step()
+    torch.cuda.synchronize(); dt = (time.time() - t0) / N
+    print(f"graph replay B={B} S={S}: {dt*1e3:.1f} ms/step, {B/dt:.2f} img/s, {B*fl/dt/1e12:.1f} TFLOP/s, loss {float(sl.detach()):.4f}")

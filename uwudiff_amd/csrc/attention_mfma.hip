@@ -207,12 +207,28 @@ constexpr int BWD_LDS = BWD_OFF_KT + 32768;
 // (16 lanes = 16 consecutive rows, same chunk) hit 16 distinct slots of the 256-B bank row.
 __device__ __forceinline__ int off512(int row, int chunk) { return row * 512 + ((chunk ^ (row & 15)) << 4); }
 
+// DQ = true (T <= 256): one workgroup per head owns all keys and also forms dQ (phase 2).
+// DQ = false (longer sequences): a workgroup owns one block of 256 keys of a head, walks all query tiles and produces
+// only dK / dV for its keys (no dS image, no K^T image: 65 KB of LDS, two workgroups per CU); dQ comes from
+// attn_bwd_dq_mfma.  The key blocks of a head sit next to each other in an XCD-aware 1-D grid (they read the same Q / dO).
+template <bool DQ>
 __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int bh = blockIdx.x, b = bh / a.H, hd = bh - b * a.H;
-  const int k0 = wave * 32;
+  int bh, kblk = 0;
+  if constexpr (DQ) {
+    bh = blockIdx.x;
+  } else {
+    const int nkb = (a.T + 255) / 256, total = nkb * a.B * a.H;
+    const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+    const int q = total >> 3, rm = total & 7;
+    const int lid = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + loc;
+    bh = lid / nkb;
+    kblk = lid - bh * nkb;
+  }
+  const int b = bh / a.H, hd = bh - b * a.H;
+  const int k0 = kblk * 256 + wave * 32;
   const bool active = k0 < a.T;  // wave-uniform
   const bf16_t* qb = a.q + (int64_t)b * a.T * a.ldq + hd * 64;
   const bf16_t* kb = a.k + (int64_t)b * a.T * a.ldk + hd * 64;
@@ -225,6 +241,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
   char* ktimg = smem + BWD_OFF_KT;
 
   // K^T image for the dQ product: [d][key], natural key order, built once (4 keys x 4 d per thread-step)
+  if constexpr (DQ)
   for (int kt64 = tid >> 8; kt64 * 64 < a.T; kt64 += 2) {
     TStage ks;
     const int t256 = tid & 255;
@@ -332,7 +349,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
           }
         }
         // dS -> shared image [q][key] (the one transpose: dQ contracts over the lane index)
-        {
+        if constexpr (DQ) {
           const int key = k0 + r;
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
@@ -353,9 +370,9 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
         }
       }
     }
-    __syncthreads();  // dS image complete for all keys
+    if constexpr (DQ) __syncthreads();  // dS image complete for all keys
     // ---- phase 2: dQ^T[d][q] = K^T[d][key] . dS^T[key][q]; wave w owns q-block (w&3) and d-blocks 2(w>>2), +1
-    {
+    if constexpr (DQ) {
       const int qblk = wave & 3;
       bf16_t* dqrow = a.dq + (int64_t)b * a.T * a.ldq + hd * 64 + (int64_t)(t * 64 + 16 * qblk + fr) * a.ldq;
 #pragma unroll
@@ -390,6 +407,130 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------- dQ, long sequences
+// Query-owner pass (structure of the forward kernel): 4 waves x 32 query rows, 64-key tiles of K (row-major), V
+// (row-major) and K^T (transposing stager) through LDS.  With the query on the lane,
+//   S^T[key][q] = K . Q^T,  dP^T[key][q] = V . dO^T   (Q / dO fragments of the wave's rows live in registers)
+//   dS^T = P^T (dP^T - delta[q]),  P^T = exp2(c S^T - lse[q])      (lse / delta are per-lane scalars)
+//   dQ^T[d][q] += K^T[d][key] . dS^T[key][q]              (dS^T accumulator reused as the B operand, as P^T in forward)
+// so dQ accumulates over all key tiles in the wave's own registers: no atomics, no cross-workgroup reduction.
+// delta[q] = sum_d dO O is formed from the wave's own dO fragments and the matching O chunks.
+__global__ void __launch_bounds__(256, 2) attn_bwd_dq_mfma(const MArgs a) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 24576];  // 2 stages x (K 8 KB | V 8 KB | K^T 8 KB)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int ntq = (a.T + 127) / 128, total = ntq * a.B * a.H;
+  int lid;
+  {
+    const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+    const int q = total >> 3, rm = total & 7;
+    lid = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + loc;
+  }
+  const int bh = lid / ntq, b = bh / a.H, hd = bh - b * a.H;
+  const int q0 = (lid - bh * ntq) * 128 + wave * 32;
+  const bool active = q0 < a.T;  // wave-uniform
+  const bf16_t* qb = a.q + (int64_t)b * a.T * a.ldq + hd * 64;
+  const bf16_t* kb = a.k + (int64_t)b * a.T * a.ldk + hd * 64;
+  const bf16_t* vb = a.v + (int64_t)b * a.T * a.ldv + hd * 64;
+  const bf16_t* gb = a.dO + (int64_t)b * a.T * a.ldo + hd * 64;
+  const bf16_t* ob = a.o + (int64_t)b * a.T * a.ldo + hd * 64;
+  const float c = a.scale * 1.4426950408889634f;
+
+  uint4 qf[4], gf[4];
+  float lq = 0.f, dl = 0.f;
+  if (active) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      qf[s] = *reinterpret_cast<const uint4*>(qb + (int64_t)(q0 + r) * a.ldq + 16 * s + 8 * h);
+      gf[s] = *reinterpret_cast<const uint4*>(gb + (int64_t)(q0 + r) * a.ldo + 16 * s + 8 * h);
+      const uint4 of = *reinterpret_cast<const uint4*>(ob + (int64_t)(q0 + r) * a.ldo + 16 * s + 8 * h);
+      const bf16x8 gv = *reinterpret_cast<const bf16x8*>(&gf[s]), ov = *reinterpret_cast<const bf16x8*>(&of);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dl += (float)gv[j] * (float)ov[j];
+    }
+    dl += __shfl_xor(dl, 32, 64);  // the two lane halves hold the two halves of the row
+    lq = a.lse[((int64_t)b * a.H + hd) * a.T + q0 + r] * 1.4426950408889634f;
+  }
+  f32x16 dq[2];
+  dq[0] = dq[1] = f32x16{};
+
+  uint4 kreg[2], vreg[2];
+  TStage ktreg;
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      kreg[p] = *reinterpret_cast<const uint4*>(kb + (int64_t)(k0 + (tid >> 3) + 32 * p) * a.ldk + 8 * (tid & 7));
+      vreg[p] = *reinterpret_cast<const uint4*>(vb + (int64_t)(k0 + (tid >> 3) + 32 * p) * a.ldv + 8 * (tid & 7));
+    }
+    ktreg.load(kb, a.ldk, k0, tid);
+  };
+  auto store_tile = [&](char* st) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      *reinterpret_cast<uint4*>(st + swz((tid >> 3) + 32 * p, tid & 7)) = kreg[p];
+      *reinterpret_cast<uint4*>(st + 8192 + swz((tid >> 3) + 32 * p, tid & 7)) = vreg[p];
+    }
+    ktreg.store(st + 16384, tid);
+  };
+
+  const int nt = a.T / 64;
+  load_tile(0);
+  store_tile(smem);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const char* Ks = smem + (t & 1) * 24576;
+    const char* Vs = Ks + 8192;
+    const char* KTs = Ks + 16384;
+    if (t + 1 < nt) load_tile((t + 1) * 64);
+    if (active) {
+      f32x16 s[2], dp[2];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        s[kt] = f32x16{};
+        dp[kt] = f32x16{};
+#pragma unroll
+        for (int ss = 0; ss < 4; ++ss) {
+          const uint4 kf = *reinterpret_cast<const uint4*>(Ks + swz(32 * kt + r, 2 * ss + h));
+          const uint4 vf = *reinterpret_cast<const uint4*>(Vs + swz(32 * kt + r, 2 * ss + h));
+          s[kt] = mfma32(kf, qf[ss], s[kt]);
+          dp[kt] = mfma32(vf, gf[ss], dp[kt]);
+        }
+      }
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float p = fexp2(s[kt][i] * c - lq);
+          s[kt][i] = p * (dp[kt][i] - dl);
+        }
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const uint4 dsf = pack8(s[kt], s2);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const uint4 ktf = *reinterpret_cast<const uint4*>(KTs + swz(32 * dt + r, 2 * (2 * kt + s2) + h));
+            dq[dt] = mfma32(ktf, dsf, dq[dt]);
+          }
+        }
+    }
+    if (t + 1 < nt) store_tile(smem + ((t + 1) & 1) * 24576);
+    __syncthreads();
+  }
+  if (active) {
+    bf16_t* dqb = a.dq + (int64_t)b * a.T * a.ldq + hd * 64 + (int64_t)(q0 + r) * a.ldq;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int d0 = 32 * dt + 8 * g4 + 4 * h;
+        store4(dqb + d0, f32x4{dq[dt][4 * g4] * a.scale, dq[dt][4 * g4 + 1] * a.scale, dq[dt][4 * g4 + 2] * a.scale,
+                               dq[dt][4 * g4 + 3] * a.scale});
+      }
+  }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------- host side
@@ -397,7 +538,7 @@ bool uwu_attn_mfma_fwd_ok(int Tq, int Tk, int d, int ldq, int ldk, int ldv, int 
   return d == 64 && Tq == Tk && Tq % 64 == 0 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0;
 }
 bool uwu_attn_mfma_bwd_ok(int Tq, int Tk, int d, int ldq, int ldk, int ldv, int ldo) {
-  return uwu_attn_mfma_fwd_ok(Tq, Tk, d, ldq, ldk, ldv, ldo) && Tq <= 256;
+  return uwu_attn_mfma_fwd_ok(Tq, Tk, d, ldq, ldk, ldv, ldo);
 }
 
 int uwu_attn_mfma_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int T, int H, int ldq,
@@ -418,10 +559,13 @@ int uwu_attn_mfma_bwd(const void* q, const void* k, const void* v, const void* o
   UWU_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)dO | (uintptr_t)dq |
                   (uintptr_t)dk | (uintptr_t)dv) & 15) == 0,
                 "attention_bwd(mfma): tensors must be 16-byte aligned");
+  constexpr int LDS_KV = BWD_OFF_LSE + 1024;  // key-block variant: the two staging stages + lse / delta
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              BWD_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_KV);
     attr_done = true;
   }
   (void)delta;  // the row sums of dO * O are formed inside the kernel
@@ -430,7 +574,12 @@ int uwu_attn_mfma_bwd(const void* q, const void* k, const void* v, const void* o
   a.dO = (const bf16_t*)dO; a.lse = const_cast<float*>(lse); a.delta = delta;
   a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
   a.B = B; a.T = T; a.H = H; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.scale = scale;
-  hipLaunchKernelGGL(attn_bwd_mfma, dim3(B * H), dim3(512), BWD_LDS, st, a);
+  if (T <= 256) {
+    hipLaunchKernelGGL(attn_bwd_mfma<true>, dim3(B * H), dim3(512), BWD_LDS, st, a);
+  } else {  // dK / dV per block of 256 keys, dQ per tile of 128 queries
+    hipLaunchKernelGGL(attn_bwd_mfma<false>, dim3(B * H * ((T + 255) / 256)), dim3(512), LDS_KV, st, a);
+    hipLaunchKernelGGL(attn_bwd_dq_mfma, dim3(B * H * ((T + 127) / 128)), dim3(256), 0, st, a);
+  }
   UWU_LAUNCH_CHECK("attention_bwd(mfma)");
   return UWU_OK;
 }
