@@ -246,9 +246,10 @@ int uwu_add_pos(void* x, const float* pos, int B, int T, int D, int dtype, void*
 /* y = GroupNorm(x; G groups, eps, gamma, beta) [then SiLU if silu]; mean/rstd: fp32 [B*G]. */
 int uwu_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                       int B, int HW, int C, int G, float eps, int silu, int dtype, void* stream);
-/* dgamma/dbeta are accumulated (fp32 atomics). */
+/* dgamma/dbeta are accumulated (fp32 atomics).  ws: fp32 scratch of 2*B*G floats (per-group sums).
+ * Both directions: C % 8 == 0, C <= 4096, 16-byte aligned tensors (whole-row vector accesses). */
 int uwu_groupnorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
-                      const float* beta, void* dx, float* dgamma, float* dbeta, int B, int HW, int C, int G,
+                      const float* beta, void* dx, float* dgamma, float* dbeta, float* ws, int B, int HW, int C, int G,
                       int silu, int dtype, void* stream);
 /* 3x3 / padding 1 / stride 1|2 convolution = im2col + uwu_gemm: col[(b,oy,ox), (ky,kx,c)]; col2im is the adjoint
  * in gather form (no atomics). */

@@ -178,3 +178,33 @@ def test_embed_and_layout_kernels():
     posd = pos.cuda()
     L.call("uwu_add_pos", L.ptr(xd), L.ptr(posd), Bi, T_, D, L.F32, L.stream())
     cmp(xd, xx + pos.repeat(Bi, 1), rtol=0, atol=1e-7)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,HW,C,silu", [(2, 64, 320, True), (3, 100, 640, False), (1, 37, 2560, True), (2, 1024, 960, True),
+                                         (1, 4096, 64, True)])
+def test_groupnorm_fwd_bwd(B, HW, C, silu, dtype):
+    """uwu_groupnorm_fwd/bwd (channels-last, 32 groups) vs torch.nn.functional.group_norm (+ SiLU) in fp32."""
+    from uwudiff_amd import ops
+
+    torch.manual_seed(0)
+    G = 32
+    x = (torch.randn(B, HW, C) * 1.3 + 0.4).to(dtype)
+    gamma, beta = torch.randn(C) * 0.5 + 1.0, torch.randn(C) * 0.3
+    dy = torch.randn(B, HW, C).to(dtype)
+    xr = x.float().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    yr = F.group_norm(xr.transpose(1, 2), G, gr, br, eps=1e-5).transpose(1, 2)
+    if silu:
+        yr = F.silu(yr)
+    yr.backward(dy.float())
+    xd = x.cuda().reshape(B * HW, C)
+    y, mean, rstd = ops.groupnorm_fwd(xd, gamma.cuda(), beta.cuda(), B, HW, C, G, 1e-5, silu)
+    dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    dx = ops.groupnorm_bwd(dy.cuda().reshape(B * HW, C), xd, mean, rstd, gamma.cuda(), beta.cuda(), dg, db, B, HW, C, G, silu)
+    t = dict(rtol=2e-4, atol=2e-4) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+    cmp(y.reshape(B, HW, C), yr, **t)
+    cmp(dx.reshape(B, HW, C), xr.grad, **t)
+    tg = dict(rtol=1e-3, atol=1e-3 * HW ** 0.5) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2 * (B * HW) ** 0.5)
+    cmp(dg, gr.grad, **tg)
+    cmp(db, br.grad, **tg)

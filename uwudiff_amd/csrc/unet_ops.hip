@@ -6,96 +6,7 @@
 
 namespace {
 
-// ---- GroupNorm (+ optional SiLU), one workgroup per (sample, group) ---------------------------------------
-// x, y: [B, HW, C]; group g owns channels [g*cpg, (g+1)*cpg).  Two passes over the group's HW*cpg elements
-// (kept simple: the group of SDXL's largest level is 1024 px * 10 ch = 20 KB and stays in L2).
-template <typename T>
-__global__ void __launch_bounds__(256) groupnorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, T* __restrict__ y,
-                                                            float* __restrict__ mean_o, float* __restrict__ rstd_o,
-                                                            int HW, int C, int G, float eps, int silu) {
-  __shared__ float red[4];
-  const int b = blockIdx.x / G, g = blockIdx.x - b * G;
-  const int cpg = C / G;
-  const int64_t base = (int64_t)b * HW * C + g * cpg;
-  const int n = HW * cpg;
-  float s = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const int p = i / cpg, c = i - p * cpg;
-    s += to_f32(x[base + (int64_t)p * C + c]);
-  }
-  const float mean = block_sum<4>(s, red) / (float)n;
-  float q = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const int p = i / cpg, c = i - p * cpg;
-    const float d = to_f32(x[base + (int64_t)p * C + c]) - mean;
-    q += d * d;
-  }
-  const float var = block_sum<4>(q, red) / (float)n;
-  const float rstd = 1.f / sqrtf(var + eps);
-  if (threadIdx.x == 0) {
-    mean_o[blockIdx.x] = mean;
-    rstd_o[blockIdx.x] = rstd;
-  }
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const int p = i / cpg, c = i - p * cpg;
-    const int ch = g * cpg + c;
-    float v = (to_f32(x[base + (int64_t)p * C + c]) - mean) * rstd * gamma[ch] + beta[ch];
-    if (silu) v = silu_f(v);
-    y[base + (int64_t)p * C + c] = from_f32<T>(v);
-  }
-}
-
-// dx, dgamma, dbeta.  z = xhat*gamma + beta ; y = silu(z) (optional).
-// Pass 1 walks the group channel by channel (block reductions; LDS float atomics serialise and were measured
-// 5x slower than a whole attention kernel, so none are used), pass 2 writes dx.
-template <typename T>
-__global__ void __launch_bounds__(256) groupnorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
-                                                            const float* __restrict__ mean_i,
-                                                            const float* __restrict__ rstd_i,
-                                                            const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, T* __restrict__ dx,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            int HW, int C, int G, int silu) {
-  __shared__ float red[4];
-  const int b = blockIdx.x / G, g = blockIdx.x - b * G;
-  const int cpg = C / G;
-  const int64_t base = (int64_t)b * HW * C + g * cpg;
-  const int n = HW * cpg;
-  const float mean = mean_i[blockIdx.x], rstd = rstd_i[blockIdx.x];
-  float s1 = 0.f, s2 = 0.f;
-  for (int c = 0; c < cpg; ++c) {
-    const int ch = g * cpg + c;
-    const float gm = gamma[ch], bt = beta[ch];
-    float a = 0.f, bsum = 0.f;
-    for (int p = threadIdx.x; p < HW; p += 256) {
-      const float xh = (to_f32(x[base + (int64_t)p * C + c]) - mean) * rstd;
-      float go = to_f32(dy[base + (int64_t)p * C + c]);
-      if (silu) go *= dsilu_f(xh * gm + bt);
-      a += go * xh;
-      bsum += go;
-    }
-    a = block_sum<4>(a, red);
-    bsum = block_sum<4>(bsum, red);
-    if (threadIdx.x == 0) {
-      atomicAdd(dgamma + ch, a);
-      atomicAdd(dbeta + ch, bsum);
-    }
-    s1 += gm * bsum;
-    s2 += gm * a;
-  }
-  s1 /= (float)n;
-  s2 /= (float)n;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const int p = i / cpg, c = i - p * cpg;
-    const int ch = g * cpg + c;
-    const float xh = (to_f32(x[base + (int64_t)p * C + c]) - mean) * rstd;
-    float go = to_f32(dy[base + (int64_t)p * C + c]);
-    if (silu) go *= dsilu_f(xh * gamma[ch] + beta[ch]);
-    dx[base + (int64_t)p * C + c] = from_f32<T>(rstd * (go * gamma[ch] - s1 - xh * s2));
-  }
-}
-
+// (GroupNorm lives in groupnorm.hip)
 // ---- im2col / col2im for 3x3, padding 1, stride 1 or 2 (channels-last) ----------------------------------
 // col[(b, oy, ox), (ky, kx, c)] = x[b, oy*s + ky - 1, ox*s + kx - 1, c]   (zero outside)
 template <typename T>
@@ -253,38 +164,6 @@ __global__ void __launch_bounds__(256) layout_kernel(float* __restrict__ nchw, T
   if ((dtype) == UWU_F32) { EXPR_F32; }                              \
   else if ((dtype) == UWU_BF16) { EXPR_BF16; }                       \
   else { uwu_set_error("bad dtype %d", (int)(dtype)); return UWU_EINVAL; }
-
-extern "C" int uwu_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
-                                 float* rstd, int B, int HW, int C, int G, float eps, int silu, int dtype,
-                                 void* stream) {
-  UWU_CHECK_ARG(x && gamma && beta && y && mean && rstd, "groupnorm_fwd: null pointer");
-  UWU_CHECK_ARG(B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, "groupnorm_fwd: bad shape C=%d G=%d", C, G);
-  hipStream_t st = (hipStream_t)stream;
-  UNET_DISPATCH(dtype,
-                hipLaunchKernelGGL((groupnorm_fwd_kernel<float>), dim3(B * G), dim3(256), 0, st, (const float*)x, gamma,
-                                   beta, (float*)y, mean, rstd, HW, C, G, eps, silu),
-                hipLaunchKernelGGL((groupnorm_fwd_kernel<bf16_t>), dim3(B * G), dim3(256), 0, st, (const bf16_t*)x,
-                                   gamma, beta, (bf16_t*)y, mean, rstd, HW, C, G, eps, silu))
-  UWU_LAUNCH_CHECK("groupnorm_fwd");
-  return UWU_OK;
-}
-
-extern "C" int uwu_groupnorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd,
-                                 const float* gamma, const float* beta, void* dx, float* dgamma, float* dbeta, int B,
-                                 int HW, int C, int G, int silu, int dtype, void* stream) {
-  UWU_CHECK_ARG(dy && x && mean && rstd && gamma && beta && dx && dgamma && dbeta, "groupnorm_bwd: null pointer");
-  UWU_CHECK_ARG(B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, "groupnorm_bwd: bad shape");
-  hipStream_t st = (hipStream_t)stream;
-  const size_t lds = 0;
-  UNET_DISPATCH(dtype,
-                hipLaunchKernelGGL((groupnorm_bwd_kernel<float>), dim3(B * G), dim3(256), lds, st, (const float*)dy,
-                                   (const float*)x, mean, rstd, gamma, beta, (float*)dx, dgamma, dbeta, HW, C, G, silu),
-                hipLaunchKernelGGL((groupnorm_bwd_kernel<bf16_t>), dim3(B * G), dim3(256), lds, st, (const bf16_t*)dy,
-                                   (const bf16_t*)x, mean, rstd, gamma, beta, (bf16_t*)dx, dgamma, dbeta, HW, C, G,
-                                   silu))
-  UWU_LAUNCH_CHECK("groupnorm_bwd");
-  return UWU_OK;
-}
 
 extern "C" int uwu_im2col3x3(const void* x, void* col, int B, int H, int W, int C, int stride, int dtype, void* stream) {
   UWU_CHECK_ARG(x && col && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && (stride == 1 || stride == 2),

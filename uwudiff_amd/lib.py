@@ -75,7 +75,7 @@ _SIGS = {
     "uwu_unpatchify": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     "uwu_add_pos": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "uwu_groupnorm_fwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_int, c_int, P]),
-    "uwu_groupnorm_bwd": (c_int, [P] * 9 + [c_int] * 6 + [P]),
+    "uwu_groupnorm_bwd": (c_int, [P] * 10 + [c_int] * 6 + [P]),
     "uwu_im2col3x3": (c_int, [P, P] + [c_int] * 6 + [P]),
     "uwu_col2im3x3": (c_int, [P, P] + [c_int] * 6 + [P]),
     "uwu_geglu_fwd": (c_int, [P, P, c_int64, c_int, c_int, P]),

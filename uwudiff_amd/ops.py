@@ -112,8 +112,9 @@ def groupnorm_fwd(x, gamma, beta, B, HW, C, G, eps, silu):
 
 def groupnorm_bwd(dy, x, mean, rstd, gamma, beta, dgamma, dbeta, B, HW, C, G, silu):
     dx = torch.empty_like(x)
+    ws = torch.empty(2 * B * G, device=x.device, dtype=torch.float32)
     L.call("uwu_groupnorm_bwd", L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), _p(gamma), _p(beta), L.ptr(dx),
-           _p(dgamma), _p(dbeta), B, HW, C, G, int(silu), L.dt(x), L.stream())
+           _p(dgamma), _p(dbeta), L.ptr(ws), B, HW, C, G, int(silu), L.dt(x), L.stream())
     return dx
 
 
