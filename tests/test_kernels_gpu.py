@@ -84,7 +84,8 @@ def test_plain_ln_no_residual(dtype):
                                                  (2, 100, 40, 3, 72, False), (1, 128, 128, 2, 32, True),
                                                  (3, 64, 64, 2, 64, True), (2, 128, 128, 3, 64, True),
                                                  (1, 192, 192, 1, 64, False), (1, 512, 512, 2, 64, True),
-                                                 (1, 1024, 1024, 3, 64, True), (2, 320, 320, 2, 64, False)])
+                                                 (1, 1024, 1024, 3, 64, True), (2, 320, 320, 2, 64, False),
+                                                 (2, 1024, 77, 3, 64, False), (1, 256, 300, 2, 64, False), (2, 64, 13, 1, 64, False)])
 def test_attention_fwd_bwd(B, Tq, Tk, H, d, packed, dtype):
     from uwudiff_amd import ops
 

@@ -43,7 +43,7 @@ struct MArgs {
   bf16_t *out, *dq, *dk, *dv;
   float* lse;
   float* delta;
-  int B, T, H, ldq, ldk, ldv, ldo;
+  int B, T, Tk, H, ldq, ldk, ldv, ldo;  // T = queries, Tk = keys (== T for self-attention)
   float scale;
 };
 
@@ -51,11 +51,16 @@ struct MArgs {
 // Transposed staging of the same tile into a [64 cols][64 rows-permuted] image: 256 threads, each 4 rows x 4 cols.
 struct TStage {
   uint2 r[4];
-  __device__ __forceinline__ void load(const bf16_t* __restrict__ base, int ld, int row0, int t256) {
+  // rows past `nrows` are clamped to the last one (cross-attention key tiles: their scores are masked)
+  __device__ __forceinline__ void load(const bf16_t* __restrict__ base, int ld, int row0, int t256,
+                                       int nrows = 0x7fffffff) {
     const int cg = t256 & 15, rq = t256 >> 4;  // cols 4cg..4cg+3, rows 4rq..4rq+3
 #pragma unroll
-    for (int kr = 0; kr < 4; ++kr)
-      r[kr] = *reinterpret_cast<const uint2*>(base + (int64_t)(row0 + 4 * rq + kr) * ld + 4 * cg);
+    for (int kr = 0; kr < 4; ++kr) {
+      int row = row0 + 4 * rq + kr;
+      if (row >= nrows) row = nrows - 1;
+      r[kr] = *reinterpret_cast<const uint2*>(base + (int64_t)row * ld + 4 * cg);
+    }
   }
   __device__ __forceinline__ void store(char* __restrict__ lds, int t256) const {
     const int cg = t256 & 15, rq = t256 >> 4;
@@ -94,8 +99,8 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_mfma(const MArgs a) {
   const int q0 = (lid - bh * ntq) * 128 + wave * 32;
   const bool active = q0 < a.T;  // wave-uniform
   const bf16_t* qb = a.q + (int64_t)b * a.T * a.ldq + hd * 64;
-  const bf16_t* kb = a.k + (int64_t)b * a.T * a.ldk + hd * 64;
-  const bf16_t* vb = a.v + (int64_t)b * a.T * a.ldv + hd * 64;
+  const bf16_t* kb = a.k + (int64_t)b * a.Tk * a.ldk + hd * 64;
+  const bf16_t* vb = a.v + (int64_t)b * a.Tk * a.ldv + hd * 64;
   const float c = a.scale * 1.4426950408889634f;
 
   uint4 qf[4];
@@ -112,9 +117,12 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_mfma(const MArgs a) {
   TStage vreg;
   auto load_tile = [&](int k0) {
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
-      kreg[p] = *reinterpret_cast<const uint4*>(kb + (int64_t)(k0 + (tid >> 3) + 32 * p) * a.ldk + 8 * (tid & 7));
-    vreg.load(vb, a.ldv, k0, tid);
+    for (int p = 0; p < 2; ++p) {
+      int row = k0 + (tid >> 3) + 32 * p;
+      if (row >= a.Tk) row = a.Tk - 1;  // keys past Tk: clamped, masked below
+      kreg[p] = *reinterpret_cast<const uint4*>(kb + (int64_t)row * a.ldk + 8 * (tid & 7));
+    }
+    vreg.load(vb, a.ldv, k0, tid, a.Tk);
   };
   auto store_tile = [&](char* st) {
 #pragma unroll
@@ -122,7 +130,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_mfma(const MArgs a) {
     vreg.store(st + 8192, tid);
   };
 
-  const int nt = a.T / 64;
+  const int nt = (a.Tk + 63) / 64;
   load_tile(0);
   store_tile(smem);
   __syncthreads();
@@ -140,6 +148,13 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_mfma(const MArgs a) {
           uint4 kf = *reinterpret_cast<const uint4*>(Ks + swz(32 * kt + r, 2 * ss + h));
           s[kt] = mfma32(kf, qf[ss], s[kt]);
         }
+      }
+      if ((t + 1) * 64 > a.Tk) {  // ragged last key tile (cross-attention, Tk = 77): keys past Tk score -inf
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            if (t * 64 + 32 * kt + (i & 3) + 8 * (i >> 2) + 4 * h >= a.Tk) s[kt][i] = -INFINITY;
       }
       float mx = s[0][0];
 #pragma unroll
@@ -220,7 +235,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
   if constexpr (DQ) {
     bh = blockIdx.x;
   } else {
-    const int nkb = (a.T + 255) / 256, total = nkb * a.B * a.H;
+    const int nkb = (a.Tk + 255) / 256, total = nkb * a.B * a.H;
     const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
     const int q = total >> 3, rm = total & 7;
     const int lid = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + loc;
@@ -229,10 +244,11 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
   }
   const int b = bh / a.H, hd = bh - b * a.H;
   const int k0 = kblk * 256 + wave * 32;
-  const bool active = k0 < a.T;  // wave-uniform
+  const bool active = k0 < a.Tk;  // wave-uniform
+  const bool kvalid = k0 + r < a.Tk;  // this lane's key exists (ragged last block of cross-attention)
   const bf16_t* qb = a.q + (int64_t)b * a.T * a.ldq + hd * 64;
-  const bf16_t* kb = a.k + (int64_t)b * a.T * a.ldk + hd * 64;
-  const bf16_t* vb = a.v + (int64_t)b * a.T * a.ldv + hd * 64;
+  const bf16_t* kb = a.k + (int64_t)b * a.Tk * a.ldk + hd * 64;
+  const bf16_t* vb = a.v + (int64_t)b * a.Tk * a.ldv + hd * 64;
   const bf16_t* gb = a.dO + (int64_t)b * a.T * a.ldo + hd * 64;
   const bf16_t* ob = a.o + (int64_t)b * a.T * a.ldo + hd * 64;
   const float* lseb = a.lse + ((int64_t)b * a.H + hd) * a.T;
@@ -266,10 +282,11 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
   // per-wave static operands: K and V rows of this wave's 32 keys (B operands of S and dP)
   uint4 kf[4], vf[4];
   if (active) {
+    const int krow = kvalid ? k0 + r : a.Tk - 1;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      kf[s] = *reinterpret_cast<const uint4*>(kb + (int64_t)(k0 + r) * a.ldk + 16 * s + 8 * h);
-      vf[s] = *reinterpret_cast<const uint4*>(vb + (int64_t)(k0 + r) * a.ldv + 16 * s + 8 * h);
+      kf[s] = *reinterpret_cast<const uint4*>(kb + (int64_t)krow * a.ldk + 16 * s + 8 * h);
+      vf[s] = *reinterpret_cast<const uint4*>(vb + (int64_t)krow * a.ldv + 16 * s + 8 * h);
     }
   }
   f32x16 dkT[2], dvT[2];
@@ -343,7 +360,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int i = 4 * g4 + e;
-            const float p = fexp2(S[i] * c - l4[e]);
+            const float p = kvalid ? fexp2(S[i] * c - l4[e]) : 0.f;
             S[i] = p;
             dP[i] = p * (dP[i] - d4[e]);
           }
@@ -392,9 +409,9 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
     if (t + 1 < nt) store_tile((t + 1) & 1);
     __syncthreads();  // dS image free again; next stage visible
   }
-  if (active) {
-    bf16_t* dkb = a.dk + (int64_t)b * a.T * a.ldk + hd * 64 + (int64_t)(k0 + r) * a.ldk;
-    bf16_t* dvb = a.dv + (int64_t)b * a.T * a.ldv + hd * 64 + (int64_t)(k0 + r) * a.ldv;
+  if (active && kvalid) {
+    bf16_t* dkb = a.dk + (int64_t)b * a.Tk * a.ldk + hd * 64 + (int64_t)(k0 + r) * a.ldk;
+    bf16_t* dvb = a.dv + (int64_t)b * a.Tk * a.ldv + hd * 64 + (int64_t)(k0 + r) * a.ldv;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -430,8 +447,8 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_mfma(const MArgs a) {
   const int q0 = (lid - bh * ntq) * 128 + wave * 32;
   const bool active = q0 < a.T;  // wave-uniform
   const bf16_t* qb = a.q + (int64_t)b * a.T * a.ldq + hd * 64;
-  const bf16_t* kb = a.k + (int64_t)b * a.T * a.ldk + hd * 64;
-  const bf16_t* vb = a.v + (int64_t)b * a.T * a.ldv + hd * 64;
+  const bf16_t* kb = a.k + (int64_t)b * a.Tk * a.ldk + hd * 64;
+  const bf16_t* vb = a.v + (int64_t)b * a.Tk * a.ldv + hd * 64;
   const bf16_t* gb = a.dO + (int64_t)b * a.T * a.ldo + hd * 64;
   const bf16_t* ob = a.o + (int64_t)b * a.T * a.ldo + hd * 64;
   const float c = a.scale * 1.4426950408889634f;
@@ -459,10 +476,12 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_mfma(const MArgs a) {
   auto load_tile = [&](int k0) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-      kreg[p] = *reinterpret_cast<const uint4*>(kb + (int64_t)(k0 + (tid >> 3) + 32 * p) * a.ldk + 8 * (tid & 7));
-      vreg[p] = *reinterpret_cast<const uint4*>(vb + (int64_t)(k0 + (tid >> 3) + 32 * p) * a.ldv + 8 * (tid & 7));
+      int row = k0 + (tid >> 3) + 32 * p;
+      if (row >= a.Tk) row = a.Tk - 1;  // keys past Tk: clamped, their dS is zeroed below
+      kreg[p] = *reinterpret_cast<const uint4*>(kb + (int64_t)row * a.ldk + 8 * (tid & 7));
+      vreg[p] = *reinterpret_cast<const uint4*>(vb + (int64_t)row * a.ldv + 8 * (tid & 7));
     }
-    ktreg.load(kb, a.ldk, k0, tid);
+    ktreg.load(kb, a.ldk, k0, tid, a.Tk);
   };
   auto store_tile = [&](char* st) {
 #pragma unroll
@@ -473,7 +492,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_mfma(const MArgs a) {
     ktreg.store(st + 16384, tid);
   };
 
-  const int nt = a.T / 64;
+  const int nt = (a.Tk + 63) / 64;
   load_tile(0);
   store_tile(smem);
   __syncthreads();
@@ -503,6 +522,13 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_mfma(const MArgs a) {
           const float p = fexp2(s[kt][i] * c - lq);
           s[kt][i] = p * (dp[kt][i] - dl);
         }
+      if ((t + 1) * 64 > a.Tk) {  // ragged last key tile
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            if (t * 64 + 32 * kt + (i & 3) + 8 * (i >> 2) + 4 * h >= a.Tk) s[kt][i] = 0.f;
+      }
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -534,28 +560,29 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_mfma(const MArgs a) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------- host side
+// head dim 64, whole 64-row query tiles; any number of keys (ragged key tiles are masked: cross-attention, Tk = 77)
 bool uwu_attn_mfma_fwd_ok(int Tq, int Tk, int d, int ldq, int ldk, int ldv, int ldo) {
-  return d == 64 && Tq == Tk && Tq % 64 == 0 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0;
+  return d == 64 && Tk >= 1 && Tq % 64 == 0 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0;
 }
 bool uwu_attn_mfma_bwd_ok(int Tq, int Tk, int d, int ldq, int ldk, int ldv, int ldo) {
   return uwu_attn_mfma_fwd_ok(Tq, Tk, d, ldq, ldk, ldv, ldo);
 }
 
-int uwu_attn_mfma_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int T, int H, int ldq,
-                      int ldk, int ldv, int ldo, float scale, hipStream_t st) {
+int uwu_attn_mfma_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int T, int Tk, int H,
+                      int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t st) {
   UWU_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0,
                 "attention(mfma): q/k/v/o must be 16-byte aligned");
   MArgs a{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)o; a.lse = lse;
-  a.B = B; a.T = T; a.H = H; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.scale = scale;
+  a.B = B; a.T = T; a.Tk = Tk; a.H = H; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.scale = scale;
   hipLaunchKernelGGL(attn_fwd_mfma, dim3(((T + 127) / 128) * B * H), dim3(256), 0, st, a);
   UWU_LAUNCH_CHECK("attention_fwd(mfma)");
   return UWU_OK;
 }
 
 int uwu_attn_mfma_bwd(const void* q, const void* k, const void* v, const void* o, const void* dO, const float* lse,
-                      float* delta, void* dq, void* dk, void* dv, int B, int T, int H, int ldq, int ldk, int ldv,
-                      int ldo, float scale, hipStream_t st) {
+                      float* delta, void* dq, void* dk, void* dv, int B, int T, int Tk, int H, int ldq, int ldk,
+                      int ldv, int ldo, float scale, hipStream_t st) {
   UWU_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)dO | (uintptr_t)dq |
                   (uintptr_t)dk | (uintptr_t)dv) & 15) == 0,
                 "attention_bwd(mfma): tensors must be 16-byte aligned");
@@ -573,11 +600,11 @@ int uwu_attn_mfma_bwd(const void* q, const void* k, const void* v, const void* o
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o;
   a.dO = (const bf16_t*)dO; a.lse = const_cast<float*>(lse); a.delta = delta;
   a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
-  a.B = B; a.T = T; a.H = H; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.scale = scale;
-  if (T <= 256) {
+  a.B = B; a.T = T; a.Tk = Tk; a.H = H; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.scale = scale;
+  if (T == Tk && T <= 256) {
     hipLaunchKernelGGL(attn_bwd_mfma<true>, dim3(B * H), dim3(512), BWD_LDS, st, a);
   } else {  // dK / dV per block of 256 keys, dQ per tile of 128 queries
-    hipLaunchKernelGGL(attn_bwd_mfma<false>, dim3(B * H * ((T + 255) / 256)), dim3(512), LDS_KV, st, a);
+    hipLaunchKernelGGL(attn_bwd_mfma<false>, dim3(B * H * ((Tk + 255) / 256)), dim3(512), LDS_KV, st, a);
     hipLaunchKernelGGL(attn_bwd_dq_mfma, dim3(B * H * ((T + 127) / 128)), dim3(256), 0, st, a);
   }
   UWU_LAUNCH_CHECK("attention_bwd(mfma)");

@@ -305,11 +305,11 @@ static int uwu_attention_simple(const AttnArgs& a, int dtype, bool bwd, hipStrea
 // MFMA kernels (attention_mfma.hip)
 bool uwu_attn_mfma_fwd_ok(int Tq, int Tk, int d, int ldq, int ldk, int ldv, int ldo);
 bool uwu_attn_mfma_bwd_ok(int Tq, int Tk, int d, int ldq, int ldk, int ldv, int ldo);
-int uwu_attn_mfma_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int T, int H, int ldq,
-                      int ldk, int ldv, int ldo, float scale, hipStream_t st);
+int uwu_attn_mfma_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int T, int Tk, int H,
+                      int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t st);
 int uwu_attn_mfma_bwd(const void* q, const void* k, const void* v, const void* o, const void* dO, const float* lse,
-                      float* delta, void* dq, void* dk, void* dv, int B, int T, int H, int ldq, int ldk, int ldv,
-                      int ldo, float scale, hipStream_t st);
+                      float* delta, void* dq, void* dk, void* dv, int B, int T, int Tk, int H, int ldq, int ldk,
+                      int ldv, int ldo, float scale, hipStream_t st);
 static bool force_simple() {
   static int v = -1;
   if (v < 0) {
@@ -340,7 +340,7 @@ extern "C" int uwu_attention_fwd(const void* q, const void* k, const void* v, vo
   UWU_CHECK_ARG(o && lse, "attention_fwd: null output");
   if (dtype == UWU_BF16 && !force_simple() && uwu_attn_mfma_fwd_ok(Tq, Tk, d, ldq, ldk, ldv, ldo) &&
       (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0)
-    return uwu_attn_mfma_fwd(q, k, v, o, lse, B, Tq, H, ldq, ldk, ldv, ldo, scale, (hipStream_t)stream);
+    return uwu_attn_mfma_fwd(q, k, v, o, lse, B, Tq, Tk, H, ldq, ldk, ldv, ldo, scale, (hipStream_t)stream);
   AttnArgs a{};
   a.q = q; a.k = k; a.v = v; a.out = o; a.lse = lse;
   a.B = B; a.Tq = Tq; a.Tk = Tk; a.H = H; a.d = d; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
@@ -358,7 +358,7 @@ extern "C" int uwu_attention_bwd(const void* q, const void* k, const void* v, co
   if (dtype == UWU_BF16 && !force_simple() && uwu_attn_mfma_bwd_ok(Tq, Tk, d, ldq, ldk, ldv, ldo) &&
       (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)dO | (uintptr_t)dq | (uintptr_t)dk |
         (uintptr_t)dv) & 15) == 0)
-    return uwu_attn_mfma_bwd(q, k, v, o, dO, lse, delta, dq, dk, dv, B, Tq, H, ldq, ldk, ldv, ldo, scale,
+    return uwu_attn_mfma_bwd(q, k, v, o, dO, lse, delta, dq, dk, dv, B, Tq, Tk, H, ldq, ldk, ldv, ldo, scale,
                              (hipStream_t)stream);
   AttnArgs a{};
   a.q = q; a.k = k; a.v = v; a.o = o; a.dO = dO; a.lse = const_cast<float*>(lse); a.delta = delta; a.dq = dq; a.dk = dk; a.dv = dv;
