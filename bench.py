@@ -26,8 +26,10 @@ MODEL = "DiT-S/2"
 # 16 -> 3.3k, 64 -> 8.4k, 128 -> 11.1k, 256 -> 12.5k, 512 -> 13.2k, 768 -> 13.4k images/s.  512 = 22 GB of activations.
 DEFAULT_BATCH = 512
 # step GFLOP per image (3 x forward, no recompute)
-STEP_GFLOP = {"DiT-S/2": 36.3, "DiT-B/2": 138.0, "DiT-L/2": 484.0, "DiT-XL/2": 711.7}
-DESC = {"DiT-S/2": "L12 D384 h6", "DiT-B/2": "L12 D768 h12", "DiT-L/2": "L24 D1024 h16", "DiT-XL/2": "L28 D1152 h16"}
+STEP_GFLOP = {"DiT-S/2": 36.3, "DiT-B/2": 138.0, "DiT-L/2": 484.0, "DiT-XL/2": 711.7,
+              "SDXL-UNet": {32: 1283.0, 128: 20284.0}}  # the UNet2DConditionModel shape the reference YAMLs build
+DESC = {"DiT-S/2": "L12 D384 h6", "DiT-B/2": "L12 D768 h12", "DiT-L/2": "L24 D1024 h16", "DiT-XL/2": "L28 D1152 h16",
+        "SDXL-UNet": "2.57 B parameters, 77x2048 text context + text_time conditioning"}
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
 
 
@@ -90,7 +92,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--clip", type=float, default=0.0)
     ap.add_argument("--model", default=MODEL, choices=sorted(STEP_GFLOP),
-                    help="DiT preset; the headline metric (BASELINE.json) is DiT-S/2, the others are extra configs")
+                    help="denoiser; the headline metric (BASELINE.json) is DiT-S/2, the others are extra configs "
+                         "(SDXL-UNet = BASELINE config 4: give --latent 128 --batch 6)")
+    ap.add_argument("--latent", type=int, default=32, choices=[32, 128], help="latent side (DiT presets: 32)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL over xGMI) for real runs; gloo lets several ranks share ONE GPU to rehearse the "
                          "multi-process path on a 1-GPU box")
@@ -125,17 +129,28 @@ def main():
     B = args.batch
     torch.manual_seed(1215 + rank)  # configs/demo_training_latent.yaml:1 + test_train.py:69 (seed + rank)
     # random (non-zero) weights everywhere: zero-initialised gates would make whole branches numerically dead
-    model = DiT.from_config(args.model, cond_dim=1280, init="random", compute_dtype=args.dtype).to(dev)
+    unet = args.model == "SDXL-UNet"
+    if unet:
+        from uwudiff_amd.unet import UNet2DConditionModel
+
+        model = UNet2DConditionModel.from_config("sdxl", compute_dtype=args.dtype).to(dev)
+    else:
+        model = DiT.from_config(args.model, cond_dim=1280, init="random", compute_dtype=args.dtype).to(dev)
     if world > 1:  # identical replicas: broadcast rank 0's parameters
         dist.broadcast(model.flat.data, src=0)
-        model.refresh_shadow()
+        if hasattr(model, "refresh_shadow"):
+            model.refresh_shadow()
     loss_fn = DiffusionLoss(EulerDiscreteScheduler.from_pretrained("stabilityai/stable-diffusion-xl-base-1.0",
                                                                    subfolder="scheduler"))
     opt = FusedAdamW(model.parameters(), lr=1e-6, weight_decay=0.01, betas=(0.9, 0.999))
     sync = FlatGradSync(world).attach(model)  # N > 1: block gradients are reduced while the backward still runs
-    pool_n = max(4096, 2 * B)
-    pool = torch.randn(pool_n, 4, 32, 32, device=dev)          # synthetic latents resident in HBM
+    S = args.latent
+    step_gflop = STEP_GFLOP[args.model][S] if unet else STEP_GFLOP[args.model]
+    pool_n = max(4096 if S == 32 else 64, 2 * B)
+    pool = torch.randn(pool_n, 4, S, S, device=dev)            # synthetic latents resident in HBM
     pooled = torch.randn(pool_n, 1280, device=dev)             # synthetic pooled-text conditioning
+    ctx = torch.randn(B, 77, 2048, device=dev) if unet else None  # synthetic text context (77 x 2048)
+    time_ids = torch.tensor([[1024.0, 1024, 0, 0, 1024, 1024]] * B, device=dev) if unet else None
     model.flat.grad = torch.zeros_like(model.flat.data)
     step_no = [0]
 
@@ -144,7 +159,10 @@ def main():
         off = (i * B) % (pool_n - B + 1)
         x, c = pool[off:off + B], pooled[off:off + B]
         model.flat.grad.zero_()
-        loss, _ = loss_fn(x, model, added_cond_kwargs={"text_embeds": c})
+        if unet:
+            loss, _ = loss_fn(x, model, encoder_hidden_states=ctx, added_cond_kwargs={"text_embeds": c, "time_ids": time_ids})
+        else:
+            loss, _ = loss_fn(x, model, added_cond_kwargs={"text_embeds": c})
         loss.backward()
         chunks = sync.all_reduce(model.flat.grad)
         opt.param_groups[0]["lr"] = cosine_lr(1e-6, i, 100_000, 1e-7)
@@ -221,16 +239,16 @@ def main():
         imgs = B * world * args.steps
         value = imgs / elapsed
         line = {
-            "metric": f"train images/sec (whole node), {args.model} 256^2 latent", "value": round(value, 1),
+            "metric": f"train images/sec (whole node), {args.model} {'256^2 latent' if args.latent == 32 else '4x128x128 latents'}", "value": round(value, 1),
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{args.model} ({DESC[args.model]}), 4x32x32 synthetic latents + pooled-text cond 1280, "
+            "config": {"workload": f"{args.model} ({DESC[args.model]}), 4x{S}x{S} synthetic latents + pooled-text cond 1280, "
                                    f"eps-MSE, AdamW lr1e-6 wd0.01 cosine; random-init weights",
-                       "per_gpu_batch": B, "global_batch": B * world, "tokens_per_image": 256,
+                       "per_gpu_batch": B, "global_batch": B * world, "tokens_per_image": None if unet else 256,
                        "parallelism": f"dp{world}"},
-            "model_tflops": round(value * STEP_GFLOP[args.model] / 1e3, 1),
-            "mfma_frac_whole_step": round(value * STEP_GFLOP[args.model] / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
+            "model_tflops": round(value * step_gflop / 1e3, 1),
+            "mfma_frac_whole_step": round(value * step_gflop / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
             "final_loss": round(final_loss, 5),
             "roofline": roof,
         }

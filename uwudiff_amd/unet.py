@@ -84,10 +84,12 @@ class _Ctx:
         return torch.bfloat16 if self.bf16 else torch.float32
 
 
-def _wgrad_split(M, N, K, bf16):
+def _wgrad_blocks(M, N, K):
+    """workgroups the generic split-K weight-gradient kernel aims for (M tokens, N x K weight): ~3 per CU for large
+    weights, ~1 per CU when only a few output tiles exist (uwu_gemm_wgrad's fallback path; the streaming kernel picks
+    its own number of K slices)."""
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
-    ktiles = (M + (63 if bf16 else 31)) // (64 if bf16 else 32)
-    return max(1, min(((768 if tiles >= 16 else 256) + tiles - 1) // tiles, ktiles))
+    return 768 if tiles >= 16 else 256
 
 
 class _LinearFn(torch.autograd.Function):
@@ -113,10 +115,8 @@ class _LinearFn(torch.autograd.Function):
         M, K = x.shape
         N = W.shape[0]
         dx = ops.gemm(dy, W, trans_b=True) if ctx.needs_input_grad[0] else None
-        ops.gemm(dy, x, trans_a=True, trans_b=True, epilogue=L.EPI_ACCUM, out=P.g(wname),
-                 split_k=_wgrad_split(M, N, K, x.dtype == torch.bfloat16))
-        if bname:
-            ops.colsum(dy, out=P.g(bname), accumulate=True)
+        # dW += dy^T x and db += colsum(dy) in one launch where the streaming kernel takes the shape
+        ops.gemm_wgrad(dy, x, P.g(wname), blocks=_wgrad_blocks(M, N, K), bias_grad=P.g(bname) if bname else None)
         return dx, None, None, None, None, None
 
 
@@ -140,9 +140,8 @@ class _Conv3x3Fn(torch.autograd.Function):
             dcol = ops.gemm(dy, Wt, trans_b=True)
             dx = ops.col2im3x3(dcol, B, H, W_, C, stride)
         col = ops.im2col3x3(x, B, H, W_, C, stride)  # recomputed: cheaper than keeping 9x the activation
-        ops.gemm(dy, col, trans_a=True, trans_b=True, epilogue=L.EPI_ACCUM, out=P.g(wname),
-                 split_k=_wgrad_split(col.shape[0], Wt.shape[0], col.shape[1], x.dtype == torch.bfloat16))
-        ops.colsum(dy, out=P.g(bname), accumulate=True)
+        ops.gemm_wgrad(dy, col, P.g(wname), blocks=_wgrad_blocks(col.shape[0], Wt.shape[0], col.shape[1]),
+                       bias_grad=P.g(bname))
         return (dx,) + (None,) * 8
 
 
