@@ -93,12 +93,9 @@ def test_fit_tiny_unet_config_with_clip_and_snr():
 
 def test_c1_loss_curve_overlay():
     """loss-curve overlay on the plumbing config (tiny UNet, pixels, B=16).  The full 100-step
-    curves (tools/loss_curve_overlay.py) are committed as profiles/r01_loss_curve_c1_{fp32,bf16}.csv (max relative
+    curves (tests/loss_curve_overlay.py) are committed as profiles/r01_loss_curve_c1_{fp32,bf16}.csv (max relative
     deviation 2.9e-6 / 7.7e-3); the suite runs 25 steps to stay fast (the CPU oracle dominates the time)."""
-    import sys
-
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    from loss_curve_overlay import main
+    from tests.loss_curve_overlay import main
 
     rows, dev = main(steps=25, dtype="fp32")
     assert rows[-1][1] < rows[0][1]          # the oracle's loss goes down
