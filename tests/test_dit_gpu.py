@@ -80,6 +80,45 @@ def test_dit_bf16_close_to_oracle(cfg, B):
         assert l2 < 6e-2, (name, l2)
 
 
+def test_dit_bf16_full_size_batch_matches_oracle():
+    """Full-size launch shapes (M = 128 x 256 = 32768 tokens): only here do the host heuristics pick the 256x128 ring
+    GEMM, the ds_read_b64_tr_b16 input-gradient path and the streaming weight-gradient kernel with split-K scratch and
+    fused bias gradients -- end to end against the fp32 CPU oracle, same tolerances as the small bf16 case."""
+    y, yo, grads = run_pair(DIT_S, "bf16", 128, seed=3)
+    l2, _ = rel(y, yo)
+    assert l2 < 3e-2, l2
+    bad = {n: rel(g, go)[0] for n, (g, go) in grads.items() if rel(g, go)[0] >= 6e-2}
+    assert not bad, bad
+
+
+def test_dit_bench_batch_gradients_are_additive_over_samples():
+    """Size-independent property at the bench's launch shapes (per-GPU batch 512, M = 131072 tokens): the gradient of a
+    sum over samples equals the sum of the gradients of two half batches accumulated into the flat buffer (the two
+    runs take different tile counts, K-slice counts and workspace sizes)."""
+    from uwudiff_amd.dit import DiT
+
+    torch.manual_seed(11)
+    model = DiT.from_config("DiT-S/2", cond_dim=1280, init="random", compute_dtype="bf16").cuda()
+    B = 512
+    x, t = torch.randn(B, 4, 32, 32, device="cuda"), torch.randint(0, 1000, (B,), device="cuda").float()
+    c, w = torch.randn(B, 1280, device="cuda"), torch.randn(B, 4, 32, 32, device="cuda") / 4096
+
+    def grad_of(sl):
+        out = model(x[sl], t[sl], added_cond_kwargs={"text_embeds": c[sl]})[0]
+        (out * w[sl]).sum().backward()
+
+    model.flat.grad = torch.zeros_like(model.flat.data)
+    grad_of(slice(0, B))
+    full = model.flat.grad.clone()
+    model.flat.grad.zero_()
+    grad_of(slice(0, B // 2))
+    grad_of(slice(B // 2, B))
+    halves = model.flat.grad
+    l2, mx = rel(halves, full)
+    assert torch.isfinite(full).all() and float(full.abs().max()) > 0
+    assert l2 < 2e-3 and mx < 5e-3, (l2, mx)
+
+
 def test_dit_grad_accumulates_and_workspace_guard():
     from uwudiff_amd.dit import DiT, DiTConfig
 
