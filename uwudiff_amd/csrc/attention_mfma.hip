@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
     if (t + 1 < nt) load_tile((t + 1) * 64);
     // ---- phase 1: this wave's 32 keys against the 64 staged query rows
     if (active) {
-#pragma unroll 1
+#pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
         f32x16 S = {}, dP = {};
 #pragma unroll
@@ -365,18 +365,27 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
             dP[i] = p * (dP[i] - d4[e]);
           }
         }
+        // dS is rounded to bf16 ONCE (8 packed pairs): the pairs feed both the shared image and the dK operand
+        bf16x2 dsp[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dsp[j] = bf16x2{(bf16_t)dP[2 * j], (bf16_t)dP[2 * j + 1]};
         // dS -> shared image [q][key] (the one transpose: dQ contracts over the lane index)
         if constexpr (DQ) {
           const int key = k0 + r;
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const int qrow = 32 * sub + (i & 3) + 8 * (i >> 2) + 4 * h;
-            *reinterpret_cast<bf16_t*>(dsimg + off512(qrow, key >> 3) + (key & 7) * 2) = (bf16_t)dP[i];
+            *reinterpret_cast<bf16_t*>(dsimg + off512(qrow, key >> 3) + (key & 7) * 2) = dsp[i >> 1][i & 1];
           }
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          const uint4 pf = pack8(S, s2), dsf = pack8(dP, s2);
+          const uint4 pf = pack8(S, s2);
+          uint4 dsf;
+          dsf.x = *reinterpret_cast<const unsigned*>(&dsp[4 * s2]);
+          dsf.y = *reinterpret_cast<const unsigned*>(&dsp[4 * s2 + 1]);
+          dsf.z = *reinterpret_cast<const unsigned*>(&dsp[4 * s2 + 2]);
+          dsf.w = *reinterpret_cast<const unsigned*>(&dsp[4 * s2 + 3]);
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt) {
             uint4 gt = *reinterpret_cast<const uint4*>(GTs + swz(32 * dt + r, 2 * (2 * sub + s2) + h));
