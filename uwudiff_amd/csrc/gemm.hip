@@ -317,16 +317,19 @@ __device__ __forceinline__ void epilogue_tile(f32x4 (&acc)[FI][FJ], EpiPre<T, FI
 #pragma unroll
         for (int jp = 0; jp < FJ / 2; ++jp) {
           const int nb = n_w + 32 * jp;  // first column of subtile 2jp
+          // v_permlane16_swap exchanges odd 16-lane rows of its first operand with even rows of its second: with
+          // (p0, p1) = (this lane's subtile 2jp, subtile 2jp+1) an even-fq lane ends up with {own p0, partner's p0} and
+          // an odd-fq lane with {partner's p1, own p1} -- in both cases the 8 consecutive columns it stores, with no
+          // select and no trip through the LDS crossbar (ds_bpermute).
           auto exchange_store = [&](TC* dst, const f32x4& x0, const f32x4& x1, bool stream_out = false) {
             const uint2 p0 = pack(x0), p1 = pack(x1);
-            const uint2 send = odd ? p0 : p1;
-            uint2 recv;
-            recv.x = __shfl_xor(send.x, 16, 64);
-            recv.y = __shfl_xor(send.y, 16, 64);
+            typedef unsigned su32x2 __attribute__((ext_vector_type(2)));
+            const su32x2 sx = __builtin_amdgcn_permlane16_swap(p0.x, p1.x, false, false);
+            const su32x2 sy = __builtin_amdgcn_permlane16_swap(p0.y, p1.y, false, false);
             const int n = odd ? nb + 16 + 4 * (fq - 1) : nb + 4 * fq;
             if (mok && n < g.N) {
               typedef unsigned su32x4 __attribute__((ext_vector_type(4)));
-              const su32x4 o = odd ? su32x4{recv.x, recv.y, p1.x, p1.y} : su32x4{p0.x, p0.y, recv.x, recv.y};
+              const su32x4 o = su32x4{sx[0], sy[0], sx[1], sy[1]};
               su32x4* ptr = reinterpret_cast<su32x4*>(dst + (int64_t)m * g.ldc + n);
               if (stream_out) __builtin_nontemporal_store(o, ptr);
               else *ptr = o;
