@@ -278,9 +278,7 @@ __device__ __forceinline__ void epilogue_tile(f32x4 (&acc)[FI][FJ], EpiPre<T, FI
     for (int j = 0; j < FJ; ++j) {
       f32x4 v = csum[j];
 #pragma unroll
-      for (int o = 1; o < 16; o <<= 1)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += __shfl_xor(v[e], o, 64);
+      for (int e = 0; e < 4; ++e) v[e] = row16_sum(v[e]);  // over the 16 rows fr of this column group
       if (fr == 0) store4(cs_lds + wm * BNT + wn * 16 * FJ + 16 * j + 4 * fq, v);
     }
     __syncthreads();
