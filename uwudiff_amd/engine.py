@@ -81,6 +81,7 @@ class Fitter:
         self.global_rank, self.world_size, self.local_rank = _dist_env()
         self.global_step = 0
         self.history = []
+        self.step_hooks = []  # callables(fitter) run after every optimizer step (e.g. periodic save_checkpoint)
         if self.world_size > 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
@@ -93,6 +94,52 @@ class Fitter:
     @property
     def compute_dtype(self):
         return "fp32" if self.precision.startswith("32") else "bf16"
+
+    # ------------------------------------------------------------------ checkpoint / resume
+    # Lightning's checkpoint layout (the keys `Trainer.fit(ckpt_path=...)` and the reference's loader read:
+    # loader.py:24-46 extracts `state_dict` entries by prefix, e.g. "unet."): the module's state_dict carries the
+    # denoiser as `unet.<diffusers-style names>`, optimizer / scheduler states are the torch ones.
+    def save_checkpoint(self, path):
+        """Write the state of the current / last ``fit`` (rank 0 only).  Returns the dict that was saved."""
+        module, opt, sched = self._fit_state
+
+        def snap(o):  # detached CPU copy (torch's optimizer.state_dict() aliases the live state)
+            if torch.is_tensor(o):
+                return o.detach().cpu().clone()
+            if isinstance(o, dict):
+                return {k: snap(v) for k, v in o.items()}
+            if isinstance(o, (list, tuple)):
+                return type(o)(snap(v) for v in o)
+            return o
+
+        ckpt = {"epoch": 0, "global_step": self.global_step, "pytorch-lightning_version": "uwudiff_amd",
+                "state_dict": snap(dict(module.state_dict())),
+                "optimizer_states": [snap(opt.state_dict())],
+                "lr_schedulers": [sched.state_dict()] if sched is not None and hasattr(sched, "state_dict") else []}
+        if self.global_rank == 0:
+            os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+            torch.save(ckpt, path)
+        return ckpt
+
+    def load_checkpoint(self, path):
+        """Resume: parameters (+ bf16 shadow), optimizer moments / step count, scheduler, global_step."""
+        module, opt, sched = self._fit_state
+        ckpt = torch.load(path, map_location="cpu", weights_only=True)
+        sd = ckpt["state_dict"]
+        # the denoiser keeps ONE flat parameter and exposes named views: it restores itself from the `unet.*` entries;
+        # everything else (buffers such as ema_loss, other sub-modules) goes through the generic loader
+        module.unet.load_state_dict({k[len("unet."):]: v for k, v in sd.items() if k.startswith("unet.")})
+        rest = {k: v for k, v in sd.items() if not k.startswith("unet.")}
+        unexpected = module.load_state_dict(rest, strict=False).unexpected_keys
+        if unexpected:
+            raise RuntimeError(f"checkpoint has entries this trainer does not know: {unexpected[:5]}")
+        if hasattr(module.unet, "refresh_shadow"):
+            module.unet.refresh_shadow()
+        opt.load_state_dict(ckpt["optimizer_states"][0])
+        if sched is not None and ckpt.get("lr_schedulers") and hasattr(sched, "load_state_dict"):
+            sched.load_state_dict(ckpt["lr_schedulers"][0])
+        self.global_step = int(ckpt["global_step"])
+        return ckpt
 
     def _to_device(self, batch):
         x, captions, tok, added, ca = batch
@@ -114,13 +161,20 @@ class Fitter:
         opt = cfg["optimizer"] if isinstance(cfg, dict) else cfg
         sched = cfg["lr_scheduler"]["scheduler"] if isinstance(cfg, dict) and "lr_scheduler" in cfg else None
         sync = FlatGradSync(self.world_size).attach(module.unet)
+        self._fit_state = (module, opt, sched)
+        if ckpt_path is not None:
+            self.load_checkpoint(ckpt_path)
         params = [p for g in opt.param_groups for p in g["params"]]
         max_steps = 1 if self.fast_dev_run else self.max_steps
         t0 = time.time()
         epoch = 0
         done = False
+        # resume mid-epoch like Lightning does: skip the batches the interrupted epoch had already consumed
+        resume_skip = (self.global_step % max(len(loader), 1)) if ckpt_path is not None else 0
         while not done:
-            for batch in loader:
+            for bi, batch in enumerate(loader):
+                if bi < resume_skip:
+                    continue
                 if 0 <= max_steps <= self.global_step:
                     done = True
                     break
@@ -153,6 +207,8 @@ class Fitter:
                 if sched is not None:
                     sched.step()
                 self.global_step += 1
+                for hook in self.step_hooks:
+                    hook(self)
                 if self.global_step % self.log_every_n_steps == 0 or self.fast_dev_run or done:
                     rec = {"step": self.global_step, "loss": float(loss.detach()), "ema_loss": float(module.ema_loss),
                            "lr": opt.param_groups[0]["lr"], "elapsed_s": round(time.time() - t0, 3)}
@@ -160,6 +216,7 @@ class Fitter:
                     if self.global_rank == 0:
                         print(json.dumps(rec), flush=True)
             epoch += 1
+            resume_skip = 0
             if self.max_epochs is not None and epoch >= self.max_epochs:
                 break
             if max_steps < 0 and self.max_epochs is None:
