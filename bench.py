@@ -33,7 +33,7 @@ DESC = {"DiT-S/2": "L12 D384 h6", "DiT-B/2": "L12 D768 h12", "DiT-L/2": "L24 D10
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
 
 
-def cpu_baseline(batch=16, warm=1, iters=3):
+def cpu_baseline(batch=16, warm=2, iters=5):  # B=16, median of >= 5 steps after 2 warm-ups (~5 s)
     """The oracle (this build's fp32 PyTorch restatement of the same model + loss) timed on the host cores."""
     from oracle import loss as OL
     from oracle.dit import DiTOracle
@@ -79,7 +79,7 @@ def cpu_baseline(batch=16, warm=1, iters=3):
     ts.sort()
     med = ts[len(ts) // 2]
     return {"value": round(batch / med, 2), "unit": "images/s", "cores": n_thr, "kind": "port",
-            "sample": f"oracle DiT-S/2 fp32 CPU, batch {batch}, median of {iters} steps (fwd+bwd+AdamW) after {warm} warm-up"}
+            "sample": f"oracle DiT-S/2 fp32 CPU, batch {batch}, median of {iters} steps (fwd+bwd+AdamW) after {warm} warm-ups"}
 
 
 def main():
