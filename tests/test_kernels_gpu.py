@@ -209,3 +209,26 @@ def test_groupnorm_fwd_bwd(B, HW, C, silu, dtype):
     tg = dict(rtol=1e-3, atol=1e-3 * HW ** 0.5) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2 * (B * HW) ** 0.5)
     cmp(dg, gr.grad, **tg)
     cmp(db, br.grad, **tg)
+
+
+def test_c_abi_rejects_bad_arguments_without_launching():
+    """Host-side checks of the newer entry points: a bad shape / null pointer is a negative return code (UwuError with
+    the library's message), never a device fault."""
+    from uwudiff_amd import lib as L
+    from uwudiff_amd import ops
+
+    x = torch.randn(8 * 64, 36, device="cuda").bfloat16()  # C = 36: not a multiple of 8
+    g, b = torch.ones(36, device="cuda"), torch.zeros(36, device="cuda")
+    with pytest.raises(L.UwuError, match="groupnorm_fwd"):
+        ops.groupnorm_fwd(x, g, b, 8, 64, 36, 4, 1e-5, True)
+    a = torch.randn(2048, 64, device="cuda").bfloat16()
+    w = torch.randn(2048, 32, device="cuda").bfloat16()
+    dw = torch.zeros(64, 32, device="cuda")
+    with pytest.raises(L.UwuError, match="gemm_wgrad"):  # leading dimension smaller than the row length
+        L.call("uwu_gemm_wgrad", L.ptr(a), L.ptr(w), L.ptr(dw), None, 64, 32, 2048, 32, 32, 32, L.BF16, 256, None, 0,
+               L.stream())
+    with pytest.raises(L.UwuError, match="sampler_combine"):
+        L.call("uwu_sampler_combine", L.ptr(dw), None, None, None, L.ptr(dw), dw.numel(), 1.0, 0.0, 0.0, 0.0, L.stream())
+    with pytest.raises(L.UwuError, match="aggregate_concat"):
+        L.call("uwu_aggregate_concat", L.ptr(dw), L.ptr(dw), L.ptr(dw), 2, 2, 24, 3, 0, L.stream())  # elem_size 3
+    torch.cuda.synchronize()  # nothing was launched, nothing faulted
