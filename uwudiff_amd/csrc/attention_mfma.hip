@@ -360,7 +360,8 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int i = 4 * g4 + e;
-            const float p = kvalid ? fexp2(S[i] * c - l4[e]) : 0.f;
+            float p = fexp2(S[i] * c - l4[e]);
+            if constexpr (!DQ) p = kvalid ? p : 0.f;  // (self-attention with T <= 256: every key of an active wave exists)
             S[i] = p;
             dP[i] = p * (dP[i] - d4[e]);
           }
