@@ -211,6 +211,18 @@ int uwu_attention_fwd(const void* q, const void* k, const void* v, void* o, floa
 int uwu_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dO,
                       const float* lse, float* delta, void* dq, void* dk, void* dv, int B, int Tq, int Tk, int H,
                       int d, int ldq, int ldk, int ldv, int ldo, float scale, int dtype, void* stream);
+/* The same with an additive score bias per key: o = softmax(scale * Q K^T + key_bias[b, :]) V.  key_bias: fp32
+ * [B, Tk], shared by every head and query row and not differentiated -- this is how the reference applies
+ * `encoder_attention_mask` to cross-attention: `(1 - mask) * -10000.0`, unsqueezed over the query axis
+ * (rope_unet.py:440-453) and broadcast over heads by `prepare_attention_mask` (rope_unet.py:106-114) before
+ * F.scaled_dot_product_attention(attn_mask=...) (rope_unet.py:151-153).  Finite values only. */
+int uwu_attention_bias_fwd(const void* q, const void* k, const void* v, const float* key_bias, void* o, float* lse,
+                           int B, int Tq, int Tk, int H, int d, int ldq, int ldk, int ldv, int ldo, float scale,
+                           int dtype, void* stream);
+int uwu_attention_bias_bwd(const void* q, const void* k, const void* v, const float* key_bias, const void* o,
+                           const void* dO, const float* lse, float* delta, void* dq, void* dk, void* dv, int B,
+                           int Tq, int Tk, int H, int d, int ldq, int ldk, int ldv, int ldo, float scale, int dtype,
+                           void* stream);
 
 /* Axial RoPE with learnable per-head log-frequencies, exactly as the reference writes it (src/duwu/modules/rope.py:
  * 56-71, 83-108; applied to q and k at rope_unet.py:143-147).  x/y: [rows, ldx] token-major with H heads of width d;

@@ -78,10 +78,13 @@ class Attention(nn.Module):
 
     def forward(self, x, ctx=None):
         B, T, D = x.shape
+        bias = None
+        if isinstance(ctx, tuple):  # (encoder states, additive key bias [B,1,1,S]) -- rope_unet.py:106-114, 440-453
+            ctx, bias = ctx
         ctx = x if ctx is None else ctx
         q, k, v = self.to_q(x), self.to_k(ctx), self.to_v(ctx)
         q, k, v = [z.view(B, -1, self.heads, D // self.heads).transpose(1, 2) for z in (q, k, v)]
-        o = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, T, D)
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=bias).transpose(1, 2).reshape(B, T, D)
         return self.to_out[0](o)
 
 
@@ -282,6 +285,9 @@ class UNetOracle(nn.Module):
             te = sinusoid(ids.flatten(), self.add_time_dim).reshape(B, -1)
             emb = emb + self.add_embedding(torch.cat([added_cond_kwargs["text_embeds"].float(), te], dim=-1))
         ctx = encoder_hidden_states.float() if encoder_hidden_states is not None else None
+        if encoder_attention_mask is not None and ctx is not None:
+            # (1 = keep, 0 = discard) -> additive bias, as the reference's Transformer2D wrapper does (rope_unet.py:448-453)
+            ctx = (ctx, ((1 - encoder_attention_mask.float()) * -10000.0)[:, None, None, :])
         x = self.conv_in(sample.float())
         skips = [x]
         for blk in self.down_blocks:

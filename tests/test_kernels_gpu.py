@@ -125,6 +125,43 @@ def test_attention_fwd_bwd(B, Tq, Tk, H, d, packed, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,Tq,Tk,H,d", [(2, 64, 77, 2, 64), (2, 1024, 77, 3, 64), (1, 256, 256, 2, 64),
+                                         (2, 128, 300, 1, 64), (2, 100, 40, 3, 72), (3, 64, 5, 1, 32)])
+def test_attention_key_bias(B, Tq, Tk, H, d, dtype):
+    """softmax(scale QK^T + key_bias[b,:]) V -- the reference's encoder_attention_mask path: (1-m)*-10000 per key,
+    broadcast over heads and queries (rope_unet.py:106-114,448-453) -- plus a general finite bias."""
+    from uwudiff_amd import ops
+
+    torch.manual_seed(1)
+    D = H * d
+    q, k, v = (torch.randn(B * Tq, D).to(dtype), torch.randn(B * Tk, D).to(dtype), torch.randn(B * Tk, D).to(dtype))
+    do = torch.randn(B * Tq, D).to(dtype)
+    keep = (torch.rand(B, Tk) > 0.4).float()
+    keep[:, 0] = 1
+    for bias in ((1 - keep) * -10000.0, torch.randn(B, Tk) * 2):
+        def heads(t, T):
+            return t.float().reshape(B, T, H, d).transpose(1, 2)
+
+        qr, kr, vr = [heads(t, T).detach().requires_grad_(True) for t, T in ((q, Tq), (k, Tk), (v, Tk))]
+        orf = F.scaled_dot_product_attention(qr, kr, vr, attn_mask=bias[:, None, None, :])
+        orf.backward(heads(do, Tq))
+        qd, kd, vd, bd = q.cuda(), k.cuda(), v.cuda(), bias.cuda()
+        o, lse = ops.attention_fwd(qd, kd, vd, B, Tq, Tk, H, d, key_bias=bd)
+        cmp(o, orf.transpose(1, 2).reshape(B * Tq, D), **tol(dtype))
+        dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+        ops.attention_bwd(qd, kd, vd, o, do.cuda(), lse, dq, dk, dv, B, Tq, Tk, H, d, key_bias=bd)
+        for got, ref, T in ((dq, qr.grad, Tq), (dk, kr.grad, Tk), (dv, vr.grad, Tk)):
+            ref = ref.transpose(1, 2).reshape(B * T, D)
+            if dtype == torch.float32:
+                cmp(got, ref, **tol(dtype))
+            else:  # bf16 operands, sums over up to 1024 queries: bound the error against the tensor's scale
+                err = (got.float().cpu() - ref).abs().max().item()
+                assert err < 1.5e-2 * ref.abs().max().item() + 1e-3, (err, ref.abs().max().item())
+    with pytest.raises(Exception):
+        ops.attention_fwd(qd, kd, vd, B, Tq, Tk, H, d, key_bias=bd[:, :-1].contiguous())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_colsum(dtype):
     from uwudiff_amd import ops
 

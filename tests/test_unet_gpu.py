@@ -21,7 +21,7 @@ def rel(a, b):
     return ((a - b).norm() / (b.norm() + 1e-30)).item(), ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
 
 
-def run_pair(cfg, dtype, B=2, S=16, Tk=7, seed=0):
+def run_pair(cfg, dtype, B=2, S=16, Tk=7, seed=0, mask=None):
     from oracle.unet import UNetOracle
     from uwudiff_amd.unet import UNet2DConditionModel
 
@@ -44,9 +44,11 @@ def run_pair(cfg, dtype, B=2, S=16, Tk=7, seed=0):
     pooled = torch.randn(B, 16, generator=g)
     ids = torch.tensor([[1024.0, 1024, 0, 0, 1024, 1024]] * B)
     dout = torch.randn(B, cfg["out_channels"], S, S, generator=g) / (S * S)
-    yo = ora(x, t, encoder_hidden_states=ctx, added_cond_kwargs={"text_embeds": pooled, "time_ids": ids})[0]
+    yo = ora(x, t, encoder_hidden_states=ctx, encoder_attention_mask=mask,
+             added_cond_kwargs={"text_embeds": pooled, "time_ids": ids})[0]
     yo.backward(dout)
     y = model(x.cuda(), t.cuda(), encoder_hidden_states=ctx.cuda(),
+              encoder_attention_mask=None if mask is None else mask.cuda(),
               added_cond_kwargs={"text_embeds": pooled.cuda(), "time_ids": ids.cuda()})[0]
     y.backward(dout.cuda())
     torch.cuda.synchronize()
@@ -67,6 +69,25 @@ def test_unet_fp32_matches_oracle(cfg):
     sd = model.state_dict()
     for k, v in ora.state_dict().items():
         torch.testing.assert_close(sd[k].cpu(), v, rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("dtype,bar", [("fp32", 1e-3), ("bf16", 4e-2)])
+def test_unet_encoder_attention_mask(dtype, bar):
+    """encoder_attention_mask [B,S] (1 = keep) reaches the cross-attention keys as the additive bias
+    (1 - m) * -10000 (reference rope_unet.py:448-453); masked tokens must stop influencing the output."""
+    mask = torch.tensor([[1, 1, 1, 1, 0, 0, 0], [1, 0, 1, 1, 1, 1, 0]])
+    y, yo, grads, model, ora = run_pair(TINY, dtype, mask=mask)
+    l2, mx = rel(y, yo)
+    assert l2 < bar, (l2, mx)
+    gbar = 2e-3 if dtype == "fp32" else 0.12
+    bad = {n: rel(g, go)[0] for n, (g, go) in grads.items() if rel(g, go)[0] > gbar}
+    assert not bad, bad
+    y_nomask, yo_nomask, *_ = run_pair(TINY, dtype)
+    assert rel(yo, yo_nomask)[0] > 5e-2 and rel(y, y_nomask)[0] > 5e-2  # the mask matters on this input
+    with pytest.raises(ValueError):
+        model(torch.zeros(2, 4, 16, 16, device="cuda"), torch.zeros(2, device="cuda"),
+              encoder_hidden_states=torch.zeros(2, 7, 32, device="cuda"), encoder_attention_mask=torch.ones(2, 5).cuda(),
+              added_cond_kwargs={"text_embeds": torch.zeros(2, 16).cuda(), "time_ids": torch.zeros(2, 6).cuda()})
 
 
 def test_unet_bf16_close_to_oracle():

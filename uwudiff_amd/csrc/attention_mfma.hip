@@ -43,6 +43,7 @@ struct MArgs {
   bf16_t *out, *dq, *dk, *dv;
   float* lse;
   float* delta;
+  const float* kbias;  // optional additive score bias per key, fp32 [B, Tk] (same for every head and query)
   int B, T, Tk, H, ldq, ldk, ldv, ldo;  // T = queries, Tk = keys (== T for self-attention)
   float scale;
 };
@@ -82,8 +83,12 @@ struct TStage {
 };
 
 // ------------------------------------------------------------------------------------------- forward
+// BIAS: the per-key bias (in units of the raw dot product, i.e. divided by `scale`) is staged next to the key tile
+// and becomes the INITIAL value of the score accumulator, so the softmax code is the same with and without it.
+template <bool BIAS>
 __global__ void __launch_bounds__(256, 2) attn_fwd_mfma(const MArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 16384];  // 2 stages x (K 8 KB | V^T 8 KB)
+  __shared__ __attribute__((aligned(16))) float kbs[BIAS ? 128 : 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   // 1-D grid, XCD-aware: workgroups w and w+8 share an XCD (round-robin dispatch), so every XCD takes a contiguous
@@ -115,6 +120,8 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_mfma(const MArgs a) {
 
   uint4 kreg[2];
   TStage vreg;
+  float kbreg = 0.f;
+  const float inv_scale = 1.f / a.scale;
   auto load_tile = [&](int k0) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -123,16 +130,21 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_mfma(const MArgs a) {
       kreg[p] = *reinterpret_cast<const uint4*>(kb + (int64_t)row * a.ldk + 8 * (tid & 7));
     }
     vreg.load(vb, a.ldv, k0, tid, a.Tk);
+    if constexpr (BIAS)
+      if (tid < 64) kbreg = a.kbias[(int64_t)b * a.Tk + min(k0 + tid, a.Tk - 1)] * inv_scale;
   };
-  auto store_tile = [&](char* st) {
+  auto store_tile = [&](int stage) {
+    char* st = smem + stage * 16384;
 #pragma unroll
     for (int p = 0; p < 2; ++p) *reinterpret_cast<uint4*>(st + swz((tid >> 3) + 32 * p, tid & 7)) = kreg[p];
     vreg.store(st + 8192, tid);
+    if constexpr (BIAS)
+      if (tid < 64) kbs[stage * 64 + tid] = kbreg;
   };
 
   const int nt = (a.Tk + 63) / 64;
   load_tile(0);
-  store_tile(smem);
+  store_tile(0);
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
     const char* Ks = smem + (t & 1) * 16384;
@@ -143,6 +155,14 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_mfma(const MArgs a) {
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
         s[kt] = f32x16{};
+        if constexpr (BIAS) {
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 b4 = load4(kbs + (t & 1) * 64 + 32 * kt + 8 * g4 + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[kt][4 * g4 + e] = b4[e];
+          }
+        }
 #pragma unroll
         for (int ss = 0; ss < 4; ++ss) {
           uint4 kf = *reinterpret_cast<const uint4*>(Ks + swz(32 * kt + r, 2 * ss + h));
@@ -192,7 +212,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_mfma(const MArgs a) {
           }
         }
     }
-    if (t + 1 < nt) store_tile(smem + ((t + 1) & 1) * 16384);
+    if (t + 1 < nt) store_tile((t + 1) & 1);
     __syncthreads();
   }
   if (active) {
@@ -226,8 +246,10 @@ __device__ __forceinline__ int off512(int row, int chunk) { return row * 512 + (
 // DQ = false (longer sequences): a workgroup owns one block of 256 keys of a head, walks all query tiles and produces
 // only dK / dV for its keys (no dS image, no K^T image: 65 KB of LDS, two workgroups per CU); dQ comes from
 // attn_bwd_dq_mfma.  The key blocks of a head sit next to each other in an XCD-aware 1-D grid (they read the same Q / dO).
-template <bool DQ>
+// BIAS (key-block variant only): the lane's key bias / scale is the initial value of the S accumulator.
+template <bool DQ, bool BIAS>
 __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
+  static_assert(!(DQ && BIAS), "a key bias runs through the key-block variant");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -291,6 +313,9 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
   }
   f32x16 dkT[2], dvT[2];
   dkT[0] = dkT[1] = dvT[0] = dvT[1] = f32x16{};
+  float kbr = 0.f;
+  if constexpr (BIAS)
+    if (active) kbr = a.kbias[(int64_t)b * a.Tk + (kvalid ? k0 + r : a.Tk - 1)] / a.scale;
 
   // staging registers: row-major Q and dO (one 16-B chunk each), transposed Q (threads 0-255) or dO (256-511)
   // delta[q] = sum_d dO[q][d] * O[q][d] is computed here from the staged dO chunk and the matching O chunk (8 lanes
@@ -345,6 +370,10 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
         f32x16 S = {}, dP = {};
+        if constexpr (BIAS) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) S[i] = kbr;
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           uint4 qa = *reinterpret_cast<const uint4*>(Qs + swz(32 * sub + r, 2 * s + h));
@@ -442,8 +471,10 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
 //   dQ^T[d][q] += K^T[d][key] . dS^T[key][q]              (dS^T accumulator reused as the B operand, as P^T in forward)
 // so dQ accumulates over all key tiles in the wave's own registers: no atomics, no cross-workgroup reduction.
 // delta[q] = sum_d dO O is formed from the wave's own dO fragments and the matching O chunks.
+template <bool BIAS>
 __global__ void __launch_bounds__(256, 2) attn_bwd_dq_mfma(const MArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 24576];  // 2 stages x (K 8 KB | V 8 KB | K^T 8 KB)
+  __shared__ __attribute__((aligned(16))) float kbs[BIAS ? 128 : 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int ntq = (a.T + 127) / 128, total = ntq * a.B * a.H;
@@ -483,6 +514,8 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_mfma(const MArgs a) {
 
   uint4 kreg[2], vreg[2];
   TStage ktreg;
+  float kbreg = 0.f;
+  const float inv_scale = 1.f / a.scale;
   auto load_tile = [&](int k0) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -492,19 +525,24 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_mfma(const MArgs a) {
       vreg[p] = *reinterpret_cast<const uint4*>(vb + (int64_t)row * a.ldv + 8 * (tid & 7));
     }
     ktreg.load(kb, a.ldk, k0, tid, a.Tk);
+    if constexpr (BIAS)
+      if (tid < 64) kbreg = a.kbias[(int64_t)b * a.Tk + min(k0 + tid, a.Tk - 1)] * inv_scale;
   };
-  auto store_tile = [&](char* st) {
+  auto store_tile = [&](int stage) {
+    char* st = smem + stage * 24576;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       *reinterpret_cast<uint4*>(st + swz((tid >> 3) + 32 * p, tid & 7)) = kreg[p];
       *reinterpret_cast<uint4*>(st + 8192 + swz((tid >> 3) + 32 * p, tid & 7)) = vreg[p];
     }
     ktreg.store(st + 16384, tid);
+    if constexpr (BIAS)
+      if (tid < 64) kbs[stage * 64 + tid] = kbreg;
   };
 
   const int nt = (a.Tk + 63) / 64;
   load_tile(0);
-  store_tile(smem);
+  store_tile(0);
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
     const char* Ks = smem + (t & 1) * 24576;
@@ -517,6 +555,14 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_mfma(const MArgs a) {
       for (int kt = 0; kt < 2; ++kt) {
         s[kt] = f32x16{};
         dp[kt] = f32x16{};
+        if constexpr (BIAS) {
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 b4 = load4(kbs + (t & 1) * 64 + 32 * kt + 8 * g4 + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[kt][4 * g4 + e] = b4[e];
+          }
+        }
 #pragma unroll
         for (int ss = 0; ss < 4; ++ss) {
           const uint4 kf = *reinterpret_cast<const uint4*>(Ks + swz(32 * kt + r, 2 * ss + h));
@@ -551,7 +597,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_mfma(const MArgs a) {
           }
         }
     }
-    if (t + 1 < nt) store_tile(smem + ((t + 1) & 1) * 24576);
+    if (t + 1 < nt) store_tile((t + 1) & 1);
     __syncthreads();
   }
   if (active) {
@@ -578,30 +624,34 @@ bool uwu_attn_mfma_bwd_ok(int Tq, int Tk, int d, int ldq, int ldk, int ldv, int 
   return uwu_attn_mfma_fwd_ok(Tq, Tk, d, ldq, ldk, ldv, ldo);
 }
 
-int uwu_attn_mfma_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int T, int Tk, int H,
-                      int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t st) {
+int uwu_attn_mfma_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* kbias, int B,
+                      int T, int Tk, int H, int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t st) {
   UWU_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0,
                 "attention(mfma): q/k/v/o must be 16-byte aligned");
   MArgs a{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)o; a.lse = lse;
+  a.kbias = kbias;
   a.B = B; a.T = T; a.Tk = Tk; a.H = H; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.scale = scale;
-  hipLaunchKernelGGL(attn_fwd_mfma, dim3(((T + 127) / 128) * B * H), dim3(256), 0, st, a);
+  if (kbias) hipLaunchKernelGGL(attn_fwd_mfma<true>, dim3(((T + 127) / 128) * B * H), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(attn_fwd_mfma<false>, dim3(((T + 127) / 128) * B * H), dim3(256), 0, st, a);
   UWU_LAUNCH_CHECK("attention_fwd(mfma)");
   return UWU_OK;
 }
 
 int uwu_attn_mfma_bwd(const void* q, const void* k, const void* v, const void* o, const void* dO, const float* lse,
-                      float* delta, void* dq, void* dk, void* dv, int B, int T, int Tk, int H, int ldq, int ldk,
-                      int ldv, int ldo, float scale, hipStream_t st) {
+                      float* delta, const float* kbias, void* dq, void* dk, void* dv, int B, int T, int Tk, int H,
+                      int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t st) {
   UWU_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)dO | (uintptr_t)dq |
                   (uintptr_t)dk | (uintptr_t)dv) & 15) == 0,
                 "attention_bwd(mfma): tensors must be 16-byte aligned");
   constexpr int LDS_KV = BWD_OFF_LSE + 1024;  // key-block variant: the two staging stages + lse / delta
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma<true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma<true, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma<false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma<false, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_KV);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma<false, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_KV);
     attr_done = true;
   }
@@ -610,12 +660,17 @@ int uwu_attn_mfma_bwd(const void* q, const void* k, const void* v, const void* o
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o;
   a.dO = (const bf16_t*)dO; a.lse = const_cast<float*>(lse); a.delta = delta;
   a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
+  a.kbias = kbias;
   a.B = B; a.T = T; a.Tk = Tk; a.H = H; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.scale = scale;
-  if (T == Tk && T <= 256) {
-    hipLaunchKernelGGL(attn_bwd_mfma<true>, dim3(B * H), dim3(512), BWD_LDS, st, a);
+  const dim3 gkv(B * H * ((Tk + 255) / 256)), gq(B * H * ((T + 127) / 128));
+  if (kbias) {  // biased scores: always the two-kernel form
+    hipLaunchKernelGGL((attn_bwd_mfma<false, true>), gkv, dim3(512), LDS_KV, st, a);
+    hipLaunchKernelGGL(attn_bwd_dq_mfma<true>, gq, dim3(256), 0, st, a);
+  } else if (T == Tk && T <= 256) {
+    hipLaunchKernelGGL((attn_bwd_mfma<true, false>), dim3(B * H), dim3(512), BWD_LDS, st, a);
   } else {  // dK / dV per block of 256 keys, dQ per tile of 128 queries
-    hipLaunchKernelGGL(attn_bwd_mfma<false>, dim3(B * H * ((Tk + 255) / 256)), dim3(512), LDS_KV, st, a);
-    hipLaunchKernelGGL(attn_bwd_dq_mfma, dim3(B * H * ((T + 127) / 128)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((attn_bwd_mfma<false, false>), gkv, dim3(512), LDS_KV, st, a);
+    hipLaunchKernelGGL(attn_bwd_dq_mfma<false>, gq, dim3(256), 0, st, a);
   }
   UWU_LAUNCH_CHECK("attention_bwd(mfma)");
   return UWU_OK;

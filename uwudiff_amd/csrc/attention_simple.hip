@@ -20,6 +20,7 @@ struct AttnArgs {
   void *out, *dq, *dk, *dv;
   float* lse;
   float* delta;
+  const float* kbias;  // optional additive score bias per key, fp32 [B, Tk]
   int B, Tq, Tk, H, d, ldq, ldk, ldv, ldo;
   float scale;
 };
@@ -60,6 +61,7 @@ __global__ void __launch_bounds__(128) attn_fwd_simple(const AttnArgs a) {
     }
   }
   float m = -INFINITY, l = 0.f;
+  const float* kbp = a.kbias ? a.kbias + (int64_t)b * a.Tk : nullptr;
   for (int k0 = 0; k0 < a.Tk; k0 += TILE) {
     __syncthreads();
     stage_tile(k, a.ldk, k0, a.Tk, DH, Ks);
@@ -77,7 +79,7 @@ __global__ void __launch_bounds__(128) attn_fwd_simple(const AttnArgs a) {
         p += qr[i] * kv[0] + qr[i + 1] * kv[1] + qr[i + 2] * kv[2] + qr[i + 3] * kv[3];
       }
       p += __shfl_xor(p, 1, 64);
-      s[j] = (k0 + j < a.Tk) ? p : -INFINITY;
+      s[j] = (k0 + j < a.Tk) ? (kbp ? p + kbp[k0 + j] : p) : -INFINITY;
       tmax = fmaxf(tmax, s[j]);
     }
     const float mn = fmaxf(m, tmax);
@@ -146,6 +148,7 @@ __global__ void __launch_bounds__(128) attn_bwd_dq_simple(const AttnArgs a) {
   const int64_t sidx = ((int64_t)b * a.H + h) * a.Tq + t;
   const float lse = valid ? a.lse[sidx] : 0.f;
   if (valid && half == 0) a.delta[sidx] = dl;
+  const float* kbp = a.kbias ? a.kbias + (int64_t)b * a.Tk : nullptr;
   for (int k0 = 0; k0 < a.Tk; k0 += TILE) {
     __syncthreads();
     stage_tile(k, a.ldk, k0, a.Tk, DH, Ks);
@@ -167,7 +170,7 @@ __global__ void __launch_bounds__(128) attn_bwd_dq_simple(const AttnArgs a) {
       }
       s += __shfl_xor(s, 1, 64);
       dp += __shfl_xor(dp, 1, 64);
-      const float p = (k0 + j < a.Tk) ? __expf(s * a.scale - lse) : 0.f;
+      const float p = (k0 + j < a.Tk) ? __expf(s * a.scale + (kbp ? kbp[k0 + j] : 0.f) - lse) : 0.f;
       const float ds = p * (dp - dl);
 #pragma unroll
       for (int i = 0; i < HALF; i += 4) {
@@ -215,6 +218,7 @@ __global__ void __launch_bounds__(128) attn_bwd_dkv_simple(const AttnArgs a) {
     }
   }
   const int64_t sbase = ((int64_t)b * a.H + h) * a.Tq;
+  const float kbv = (a.kbias && valid) ? a.kbias[(int64_t)b * a.Tk + t] : 0.f;
   for (int q0 = 0; q0 < a.Tq; q0 += TILE) {
     __syncthreads();
     stage_tile(q, a.ldq, q0, a.Tq, DH, Qs);
@@ -241,7 +245,7 @@ __global__ void __launch_bounds__(128) attn_bwd_dkv_simple(const AttnArgs a) {
       }
       s += __shfl_xor(s, 1, 64);
       dp += __shfl_xor(dp, 1, 64);
-      const float p = __expf(s * a.scale - lse_s[j]);
+      const float p = __expf(s * a.scale + kbv - lse_s[j]);
       const float ds = p * (dp - del_s[j]);
 #pragma unroll
       for (int i = 0; i < HALF; i += 4) {
@@ -305,11 +309,11 @@ static int uwu_attention_simple(const AttnArgs& a, int dtype, bool bwd, hipStrea
 // MFMA kernels (attention_mfma.hip)
 bool uwu_attn_mfma_fwd_ok(int Tq, int Tk, int d, int ldq, int ldk, int ldv, int ldo);
 bool uwu_attn_mfma_bwd_ok(int Tq, int Tk, int d, int ldq, int ldk, int ldv, int ldo);
-int uwu_attn_mfma_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int T, int Tk, int H,
-                      int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t st);
+int uwu_attn_mfma_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* kbias, int B,
+                      int T, int Tk, int H, int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t st);
 int uwu_attn_mfma_bwd(const void* q, const void* k, const void* v, const void* o, const void* dO, const float* lse,
-                      float* delta, void* dq, void* dk, void* dv, int B, int T, int Tk, int H, int ldq, int ldk,
-                      int ldv, int ldo, float scale, hipStream_t st);
+                      float* delta, const float* kbias, void* dq, void* dk, void* dv, int B, int T, int Tk, int H,
+                      int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t st);
 static bool force_simple() {
   static int v = -1;
   if (v < 0) {
@@ -332,37 +336,70 @@ static int check_common(const void* q, const void* k, const void* v, int B, int 
   return UWU_OK;
 }
 
-extern "C" int uwu_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int Tq,
-                                 int Tk, int H, int d, int ldq, int ldk, int ldv, int ldo, float scale, int dtype,
-                                 void* stream) {
+static int attention_fwd_impl(const void* q, const void* k, const void* v, void* o, float* lse, const float* kbias,
+                              int B, int Tq, int Tk, int H, int d, int ldq, int ldk, int ldv, int ldo, float scale,
+                              int dtype, void* stream) {
   int rc = check_common(q, k, v, B, Tq, Tk, H, d, ldq, ldk, ldv, ldo, dtype);
   if (rc) return rc;
   UWU_CHECK_ARG(o && lse, "attention_fwd: null output");
+  UWU_CHECK_ARG(scale > 0.f, "attention: scale must be positive");
   if (dtype == UWU_BF16 && !force_simple() && uwu_attn_mfma_fwd_ok(Tq, Tk, d, ldq, ldk, ldv, ldo) &&
       (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0)
-    return uwu_attn_mfma_fwd(q, k, v, o, lse, B, Tq, Tk, H, ldq, ldk, ldv, ldo, scale, (hipStream_t)stream);
+    return uwu_attn_mfma_fwd(q, k, v, o, lse, kbias, B, Tq, Tk, H, ldq, ldk, ldv, ldo, scale, (hipStream_t)stream);
   AttnArgs a{};
-  a.q = q; a.k = k; a.v = v; a.out = o; a.lse = lse;
+  a.q = q; a.k = k; a.v = v; a.out = o; a.lse = lse; a.kbias = kbias;
   a.B = B; a.Tq = Tq; a.Tk = Tk; a.H = H; a.d = d; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
   a.scale = scale;
   return uwu_attention_simple(a, dtype, false, (hipStream_t)stream);
+}
+
+static int attention_bwd_impl(const void* q, const void* k, const void* v, const void* o, const void* dO,
+                              const float* lse, float* delta, const float* kbias, void* dq, void* dk, void* dv, int B,
+                              int Tq, int Tk, int H, int d, int ldq, int ldk, int ldv, int ldo, float scale, int dtype,
+                              void* stream) {
+  int rc = check_common(q, k, v, B, Tq, Tk, H, d, ldq, ldk, ldv, ldo, dtype);
+  if (rc) return rc;
+  UWU_CHECK_ARG(o && dO && lse && delta && dq && dk && dv, "attention_bwd: null pointer");
+  UWU_CHECK_ARG(scale > 0.f, "attention: scale must be positive");
+  if (dtype == UWU_BF16 && !force_simple() && uwu_attn_mfma_bwd_ok(Tq, Tk, d, ldq, ldk, ldv, ldo) &&
+      (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)dO | (uintptr_t)dq | (uintptr_t)dk |
+        (uintptr_t)dv) & 15) == 0)
+    return uwu_attn_mfma_bwd(q, k, v, o, dO, lse, delta, kbias, dq, dk, dv, B, Tq, Tk, H, ldq, ldk, ldv, ldo, scale,
+                             (hipStream_t)stream);
+  AttnArgs a{};
+  a.q = q; a.k = k; a.v = v; a.o = o; a.dO = dO; a.lse = const_cast<float*>(lse); a.delta = delta; a.dq = dq; a.dk = dk; a.dv = dv;
+  a.kbias = kbias;
+  a.B = B; a.Tq = Tq; a.Tk = Tk; a.H = H; a.d = d; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+  a.scale = scale;
+  return uwu_attention_simple(a, dtype, true, (hipStream_t)stream);
+}
+
+extern "C" int uwu_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int Tq,
+                                 int Tk, int H, int d, int ldq, int ldk, int ldv, int ldo, float scale, int dtype,
+                                 void* stream) {
+  return attention_fwd_impl(q, k, v, o, lse, nullptr, B, Tq, Tk, H, d, ldq, ldk, ldv, ldo, scale, dtype, stream);
 }
 
 extern "C" int uwu_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dO,
                                  const float* lse, float* delta, void* dq, void* dk, void* dv, int B, int Tq, int Tk,
                                  int H, int d, int ldq, int ldk, int ldv, int ldo, float scale, int dtype,
                                  void* stream) {
-  int rc = check_common(q, k, v, B, Tq, Tk, H, d, ldq, ldk, ldv, ldo, dtype);
-  if (rc) return rc;
-  UWU_CHECK_ARG(o && dO && lse && delta && dq && dk && dv, "attention_bwd: null pointer");
-  if (dtype == UWU_BF16 && !force_simple() && uwu_attn_mfma_bwd_ok(Tq, Tk, d, ldq, ldk, ldv, ldo) &&
-      (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)dO | (uintptr_t)dq | (uintptr_t)dk |
-        (uintptr_t)dv) & 15) == 0)
-    return uwu_attn_mfma_bwd(q, k, v, o, dO, lse, delta, dq, dk, dv, B, Tq, Tk, H, ldq, ldk, ldv, ldo, scale,
-                             (hipStream_t)stream);
-  AttnArgs a{};
-  a.q = q; a.k = k; a.v = v; a.o = o; a.dO = dO; a.lse = const_cast<float*>(lse); a.delta = delta; a.dq = dq; a.dk = dk; a.dv = dv;
-  a.B = B; a.Tq = Tq; a.Tk = Tk; a.H = H; a.d = d; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
-  a.scale = scale;
-  return uwu_attention_simple(a, dtype, true, (hipStream_t)stream);
+  return attention_bwd_impl(q, k, v, o, dO, lse, delta, nullptr, dq, dk, dv, B, Tq, Tk, H, d, ldq, ldk, ldv, ldo,
+                            scale, dtype, stream);
+}
+
+extern "C" int uwu_attention_bias_fwd(const void* q, const void* k, const void* v, const float* key_bias, void* o,
+                                      float* lse, int B, int Tq, int Tk, int H, int d, int ldq, int ldk, int ldv,
+                                      int ldo, float scale, int dtype, void* stream) {
+  UWU_CHECK_ARG(key_bias, "attention_bias_fwd: null key_bias");
+  return attention_fwd_impl(q, k, v, o, lse, key_bias, B, Tq, Tk, H, d, ldq, ldk, ldv, ldo, scale, dtype, stream);
+}
+
+extern "C" int uwu_attention_bias_bwd(const void* q, const void* k, const void* v, const float* key_bias,
+                                      const void* o, const void* dO, const float* lse, float* delta, void* dq,
+                                      void* dk, void* dv, int B, int Tq, int Tk, int H, int d, int ldq, int ldk,
+                                      int ldv, int ldo, float scale, int dtype, void* stream) {
+  UWU_CHECK_ARG(key_bias, "attention_bias_bwd: null key_bias");
+  return attention_bwd_impl(q, k, v, o, dO, lse, delta, key_bias, dq, dk, dv, B, Tq, Tk, H, d, ldq, ldk, ldv, ldo,
+                            scale, dtype, stream);
 }

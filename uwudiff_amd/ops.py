@@ -55,21 +55,36 @@ def _p(t):
     return t.data_ptr()
 
 
-def attention_fwd(q, k, v, B, Tq, Tk, H, d, scale=None):
-    """q/k/v: 2-D views [B*T, >=H*d] with unit inner stride (e.g. column slices of a packed projection)."""
+def _key_bias(key_bias, B, Tk):
+    if key_bias.dtype != torch.float32 or tuple(key_bias.shape) != (B, Tk):
+        raise L.UwuError(f"key_bias must be fp32 [B, Tk] = [{B}, {Tk}], got {key_bias.dtype} {tuple(key_bias.shape)}")
+    return L.ptr(key_bias)
+
+
+def attention_fwd(q, k, v, B, Tq, Tk, H, d, scale=None, key_bias=None):
+    """q/k/v: 2-D views [B*T, >=H*d] with unit inner stride (e.g. column slices of a packed projection).
+    key_bias: optional fp32 [B, Tk] added to the scaled scores of every head and query (encoder_attention_mask)."""
     scale = scale if scale is not None else d ** -0.5
     o = torch.empty(B * Tq, H * d, device=q.device, dtype=q.dtype)
     lse = torch.empty(B, H, Tq, device=q.device, dtype=torch.float32)
-    L.call("uwu_attention_fwd", _p(q), _p(k), _p(v), L.ptr(o), L.ptr(lse), B, Tq, Tk, H, d, q.stride(0), k.stride(0),
-           v.stride(0), o.stride(0), scale, L.dt(q), L.stream())
+    tail = (L.ptr(o), L.ptr(lse), B, Tq, Tk, H, d, q.stride(0), k.stride(0), v.stride(0), o.stride(0), scale, L.dt(q),
+            L.stream())
+    if key_bias is None:
+        L.call("uwu_attention_fwd", _p(q), _p(k), _p(v), *tail)
+    else:
+        L.call("uwu_attention_bias_fwd", _p(q), _p(k), _p(v), _key_bias(key_bias, B, Tk), *tail)
     return o, lse
 
 
-def attention_bwd(q, k, v, o, do, lse, dq, dk, dv, B, Tq, Tk, H, d, scale=None):
+def attention_bwd(q, k, v, o, do, lse, dq, dk, dv, B, Tq, Tk, H, d, scale=None, key_bias=None):
     scale = scale if scale is not None else d ** -0.5
     delta = torch.empty_like(lse)
-    L.call("uwu_attention_bwd", _p(q), _p(k), _p(v), L.ptr(o), L.ptr(do), L.ptr(lse), L.ptr(delta), _p(dq), _p(dk),
-           _p(dv), B, Tq, Tk, H, d, q.stride(0), k.stride(0), v.stride(0), o.stride(0), scale, L.dt(q), L.stream())
+    tail = (L.ptr(o), L.ptr(do), L.ptr(lse), L.ptr(delta), _p(dq), _p(dk), _p(dv), B, Tq, Tk, H, d, q.stride(0),
+            k.stride(0), v.stride(0), o.stride(0), scale, L.dt(q), L.stream())
+    if key_bias is None:
+        L.call("uwu_attention_bwd", _p(q), _p(k), _p(v), *tail)
+    else:
+        L.call("uwu_attention_bias_bwd", _p(q), _p(k), _p(v), _key_bias(key_bias, B, Tk), *tail)
     return dq, dk, dv
 
 

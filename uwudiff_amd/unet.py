@@ -184,19 +184,19 @@ class _LayerNormFn(torch.autograd.Function):
 
 class _AttentionFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, B, Tq, Tk, H, d):
-        o, lse = ops.attention_fwd(q, k, v, B, Tq, Tk, H, d)
+    def forward(ctx, q, k, v, B, Tq, Tk, H, d, key_bias=None):
+        o, lse = ops.attention_fwd(q, k, v, B, Tq, Tk, H, d, key_bias=key_bias)
         ctx.save_for_backward(q, k, v, o, lse)
-        ctx.meta = (B, Tq, Tk, H, d)
+        ctx.meta = (B, Tq, Tk, H, d, key_bias)
         return o
 
     @staticmethod
     def backward(ctx, do):
         q, k, v, o, lse = ctx.saved_tensors
-        B, Tq, Tk, H, d = ctx.meta
+        B, Tq, Tk, H, d, key_bias = ctx.meta
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        ops.attention_bwd(q, k, v, o, do.contiguous(), lse, dq, dk, dv, B, Tq, Tk, H, d)
-        return dq, dk, dv, None, None, None, None, None
+        ops.attention_bwd(q, k, v, o, do.contiguous(), lse, dq, dk, dv, B, Tq, Tk, H, d, key_bias=key_bias)
+        return dq, dk, dv, None, None, None, None, None, None
 
 
 class _GegluFn(torch.autograd.Function):
@@ -551,13 +551,13 @@ class UNet2DConditionModel(nn.Module):
             x = self._linear(x, name + ".conv_shortcut")
         return _AddFn.apply(x, h)
 
-    def _attn(self, x, ctx, name, B, T, Tk, heads):
+    def _attn(self, x, ctx, name, B, T, Tk, heads, key_bias=None):
         D = x.shape[1]
         q = self._linear(x, name + ".to_q", bias=False)
         src = x if ctx is None else ctx
         k = self._linear(src, name + ".to_k", bias=False)
         v = self._linear(src, name + ".to_v", bias=False)
-        o = _AttentionFn.apply(q, k, v, B, T, Tk, heads, D // heads)
+        o = _AttentionFn.apply(q, k, v, B, T, Tk, heads, D // heads, key_bias)
         return self._linear(o, name + ".to_out.0")
 
     def _t2d(self, x, ctx, name, depth, heads, B, HW, C, Tk):
@@ -567,7 +567,8 @@ class UNet2DConditionModel(nn.Module):
             b = f"{name}.transformer_blocks.{i}"
             a = self._attn(_LayerNormFn.apply(h, self.P, b + ".norm1", 1e-5), None, b + ".attn1", B, HW, HW, heads)
             h = _AddFn.apply(h, a)
-            a = self._attn(_LayerNormFn.apply(h, self.P, b + ".norm2", 1e-5), ctx, b + ".attn2", B, HW, Tk, heads)
+            a = self._attn(_LayerNormFn.apply(h, self.P, b + ".norm2", 1e-5), ctx, b + ".attn2", B, HW, Tk, heads,
+                           self._key_bias)
             h = _AddFn.apply(h, a)
             f = self._linear(_LayerNormFn.apply(h, self.P, b + ".norm3", 1e-5), b + ".ff.net.0.proj")
             f = self._linear(_GegluFn.apply(f), b + ".ff.net.2")
@@ -580,8 +581,6 @@ class UNet2DConditionModel(nn.Module):
                 added_cond_kwargs=None, cross_attention_kwargs=None, **kw):
         if not self.flat.is_cuda:
             raise L.UwuError("UNet2DConditionModel runs on the HIP device only (no CPU fallback)")
-        if encoder_attention_mask is not None:
-            raise NotImplementedError("encoder_attention_mask is not supported by the attention kernels yet")
         cfg, P = self.cfg, self.P
         dt = P.dtype
         B, _, H, W = sample.shape
@@ -606,9 +605,16 @@ class UNet2DConditionModel(nn.Module):
             emb = _AddFn.apply(emb, aug)
         emb_act = _SiluFn.apply(emb)
         ctx, Tk = None, 0
+        self._key_bias = None
         if encoder_hidden_states is not None:
             Tk = encoder_hidden_states.shape[1]
             ctx = encoder_hidden_states.to(device=dev, dtype=dt).reshape(B * Tk, -1).contiguous()
+            if encoder_attention_mask is not None:
+                # (1 = keep, 0 = discard) -> additive score bias of the cross-attention keys (rope_unet.py:448-453)
+                if encoder_attention_mask.ndim != 2 or tuple(encoder_attention_mask.shape) != (B, Tk):
+                    raise ValueError(f"encoder_attention_mask must be [B, S] = [{B}, {Tk}]")
+                keep = encoder_attention_mask.to(device=dev, dtype=torch.float32)
+                self._key_bias = ((1.0 - keep) * -10000.0).contiguous()
         # the input needs no gradient, but every op must see a differentiable input to be recorded
         x = sample.float()
         if torch.is_grad_enabled() and not x.requires_grad:
