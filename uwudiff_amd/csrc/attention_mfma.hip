@@ -1,4 +1,9 @@
-// MFMA flash attention for gfx950 (bf16 operands, fp32 softmax/accumulate), head dim 64, self-attention.
+// MFMA flash attention for gfx950 (bf16 operands, fp32 softmax/accumulate); head dim 64 (the tuned case), 72 (DiT-XL)
+// and 128; self- and cross-attention.
+// Head dims other than 64 reuse the 64-wide machinery: every LDS image is NB = ceil(DH/64) blocks of [64][64] bf16 with
+// the same swizzle, columns past DH are zero-filled while staging, and the product loops run over NKS = ceil(DH/16)
+// contraction steps and NDT = ceil(DH/32) output tiles (d = 72: 5 and 3 instead of 4.5 and 2.25 -- the MFMAs are not
+// the bound here, the softmax VALU work is, and that does not depend on DH).
 // Replaces F.scaled_dot_product_attention fwd/bwd (reference src/duwu/modules/rope_unet.py:151-153).
 //
 // All products use v_mfma_f32_32x32x16_bf16.  Lane maps (cdna_hip_programming.md section 3):
@@ -53,14 +58,15 @@ struct MArgs {
 struct TStage {
   uint2 r[4];
   // rows past `nrows` are clamped to the last one (cross-attention key tiles: their scores are masked)
+  // columns at or past `ncols` (head dims that do not fill the 64-wide block) read as zero
   __device__ __forceinline__ void load(const bf16_t* __restrict__ base, int ld, int row0, int t256,
-                                       int nrows = 0x7fffffff) {
+                                       int nrows = 0x7fffffff, int ncols = 64) {
     const int cg = t256 & 15, rq = t256 >> 4;  // cols 4cg..4cg+3, rows 4rq..4rq+3
 #pragma unroll
     for (int kr = 0; kr < 4; ++kr) {
       int row = row0 + 4 * rq + kr;
       if (row >= nrows) row = nrows - 1;
-      r[kr] = *reinterpret_cast<const uint2*>(base + (int64_t)row * ld + 4 * cg);
+      r[kr] = (4 * cg < ncols) ? *reinterpret_cast<const uint2*>(base + (int64_t)row * ld + 4 * cg) : uint2{0u, 0u};
     }
   }
   __device__ __forceinline__ void store(char* __restrict__ lds, int t256) const {
@@ -85,10 +91,26 @@ struct TStage {
 // ------------------------------------------------------------------------------------------- forward
 // BIAS: the per-key bias (in units of the raw dot product, i.e. divided by `scale`) is staged next to the key tile
 // and becomes the INITIAL value of the score accumulator, so the softmax code is the same with and without it.
-template <bool BIAS>
+template <int DH>
+struct HeadGeom {
+  static constexpr int NB = (DH + 63) / 64;   // 64-wide LDS blocks per image
+  static constexpr int NKS = (DH + 15) / 16;  // contraction steps over the head dim (k = 16 per 32x32x16 MFMA)
+  static constexpr int NDT = (DH + 31) / 32;  // 32-row output tiles over the head dim
+};
+__device__ __forceinline__ uint4 load16_or_zero(const bf16_t* p, bool ok) {
+  return ok ? *reinterpret_cast<const uint4*>(p) : uint4{0u, 0u, 0u, 0u};
+}
+extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+
+template <bool BIAS, int DH>
 __global__ void __launch_bounds__(256, 2) attn_fwd_mfma(const MArgs a) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * 16384];  // 2 stages x (K 8 KB | V^T 8 KB)
+  using G = HeadGeom<DH>;
+  constexpr int NB = G::NB, NKS = G::NKS, NDT = G::NDT;
+  constexpr int STAGE = 2 * NB * 8192;  // K blocks | V^T blocks
+  // 2 stages; one 64-wide block fits the static limit, wider heads take dynamic LDS
+  __shared__ __attribute__((aligned(16))) char st_smem[NB == 1 ? 2 * STAGE : 16];
   __shared__ __attribute__((aligned(16))) float kbs[BIAS ? 128 : 4];
+  char* const smem = NB == 1 ? st_smem : dyn_smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   // 1-D grid, XCD-aware: workgroups w and w+8 share an XCD (round-robin dispatch), so every XCD takes a contiguous
@@ -103,41 +125,50 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_mfma(const MArgs a) {
   const int bh = lid / ntq, b = bh / a.H, hd = bh - b * a.H;
   const int q0 = (lid - bh * ntq) * 128 + wave * 32;
   const bool active = q0 < a.T;  // wave-uniform
-  const bf16_t* qb = a.q + (int64_t)b * a.T * a.ldq + hd * 64;
-  const bf16_t* kb = a.k + (int64_t)b * a.Tk * a.ldk + hd * 64;
-  const bf16_t* vb = a.v + (int64_t)b * a.Tk * a.ldv + hd * 64;
+  const bf16_t* qb = a.q + (int64_t)b * a.T * a.ldq + hd * DH;
+  const bf16_t* kb = a.k + (int64_t)b * a.Tk * a.ldk + hd * DH;
+  const bf16_t* vb = a.v + (int64_t)b * a.Tk * a.ldv + hd * DH;
   const float c = a.scale * 1.4426950408889634f;
 
-  uint4 qf[4];
+  uint4 qf[NKS];
   if (active) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
-      qf[s] = *reinterpret_cast<const uint4*>(qb + (int64_t)(q0 + r) * a.ldq + 16 * s + 8 * h);
+    for (int s = 0; s < NKS; ++s)
+      qf[s] = load16_or_zero(qb + (int64_t)(q0 + r) * a.ldq + 16 * s + 8 * h, 16 * s + 8 * h < DH);
   }
-  f32x16 o[2];
-  o[0] = o[1] = f32x16{};
+  f32x16 o[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) o[dt] = f32x16{};
   float m = -INFINITY, l = 0.f;
 
-  uint4 kreg[2];
-  TStage vreg;
+  uint4 kreg[NB][2];
+  TStage vreg[NB];
   float kbreg = 0.f;
   const float inv_scale = 1.f / a.scale;
   auto load_tile = [&](int k0) {
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      int row = k0 + (tid >> 3) + 32 * p;
-      if (row >= a.Tk) row = a.Tk - 1;  // keys past Tk: clamped, masked below
-      kreg[p] = *reinterpret_cast<const uint4*>(kb + (int64_t)row * a.ldk + 8 * (tid & 7));
+    for (int blk = 0; blk < NB; ++blk) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        int row = k0 + (tid >> 3) + 32 * p;
+        if (row >= a.Tk) row = a.Tk - 1;  // keys past Tk: clamped, masked below
+        const int col = 64 * blk + 8 * (tid & 7);
+        kreg[blk][p] = load16_or_zero(kb + (int64_t)row * a.ldk + col, col < DH);
+      }
+      vreg[blk].load(vb + 64 * blk, a.ldv, k0, tid, a.Tk, DH - 64 * blk);
     }
-    vreg.load(vb, a.ldv, k0, tid, a.Tk);
     if constexpr (BIAS)
       if (tid < 64) kbreg = a.kbias[(int64_t)b * a.Tk + min(k0 + tid, a.Tk - 1)] * inv_scale;
   };
   auto store_tile = [&](int stage) {
-    char* st = smem + stage * 16384;
+    char* st = smem + stage * STAGE;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) *reinterpret_cast<uint4*>(st + swz((tid >> 3) + 32 * p, tid & 7)) = kreg[p];
-    vreg.store(st + 8192, tid);
+    for (int blk = 0; blk < NB; ++blk) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        *reinterpret_cast<uint4*>(st + blk * 8192 + swz((tid >> 3) + 32 * p, tid & 7)) = kreg[blk][p];
+      vreg[blk].store(st + (NB + blk) * 8192, tid);
+    }
     if constexpr (BIAS)
       if (tid < 64) kbs[stage * 64 + tid] = kbreg;
   };
@@ -147,8 +178,8 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_mfma(const MArgs a) {
   store_tile(0);
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
-    const char* Ks = smem + (t & 1) * 16384;
-    const char* Vs = Ks + 8192;
+    const char* Ks = smem + (t & 1) * STAGE;
+    const char* Vs = Ks + NB * 8192;
     if (t + 1 < nt) load_tile((t + 1) * 64);
     if (active) {
       f32x16 s[2];
@@ -164,8 +195,8 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_mfma(const MArgs a) {
           }
         }
 #pragma unroll
-        for (int ss = 0; ss < 4; ++ss) {
-          uint4 kf = *reinterpret_cast<const uint4*>(Ks + swz(32 * kt + r, 2 * ss + h));
+        for (int ss = 0; ss < NKS; ++ss) {
+          uint4 kf = *reinterpret_cast<const uint4*>(Ks + (ss >> 2) * 8192 + swz(32 * kt + r, 2 * (ss & 3) + h));
           s[kt] = mfma32(kf, qf[ss], s[kt]);
         }
       }
@@ -197,7 +228,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_mfma(const MArgs a) {
       l = l * alpha + ls;
       m = mn;
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
+      for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
 #pragma unroll
@@ -206,8 +237,9 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_mfma(const MArgs a) {
         for (int s2 = 0; s2 < 2; ++s2) {
           const uint4 pf = pack8(s[kt], s2);
 #pragma unroll
-          for (int dt = 0; dt < 2; ++dt) {
-            uint4 vf = *reinterpret_cast<const uint4*>(Vs + swz(32 * dt + r, 2 * (2 * kt + s2) + h));
+          for (int dt = 0; dt < NDT; ++dt) {
+            uint4 vf = *reinterpret_cast<const uint4*>(Vs + (dt >> 1) * 8192 +
+                                                       swz(32 * (dt & 1) + r, 2 * (2 * kt + s2) + h));
             o[dt] = mfma32(vf, pf, o[dt]);
           }
         }
@@ -218,25 +250,29 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_mfma(const MArgs a) {
   if (active) {
     const float lt = l + __shfl_xor(l, 32, 64);
     const float inv = 1.f / lt;
-    bf16_t* ob = a.out + (int64_t)b * a.T * a.ldo + hd * 64 + (int64_t)(q0 + r) * a.ldo;
+    bf16_t* ob = a.out + (int64_t)b * a.T * a.ldo + hd * DH + (int64_t)(q0 + r) * a.ldo;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const int d0 = 32 * dt + 8 * g4 + 4 * h;
-        store4(ob + d0, f32x4{o[dt][4 * g4] * inv, o[dt][4 * g4 + 1] * inv, o[dt][4 * g4 + 2] * inv,
-                              o[dt][4 * g4 + 3] * inv});
+        if (DH % 32 == 0 || d0 < DH)
+          store4(ob + d0, f32x4{o[dt][4 * g4] * inv, o[dt][4 * g4 + 1] * inv, o[dt][4 * g4 + 2] * inv,
+                                o[dt][4 * g4 + 3] * inv});
       }
     if (h == 0) a.lse[((int64_t)b * a.H + hd) * a.T + q0 + r] = m * a.scale + __logf(lt);
   }
 }
 
 // ------------------------------------------------------------------------------------------- backward
-constexpr int BWD_STAGE = 32768;                    // Qs | dOs | QTs | dOTs (8 KB each)
-constexpr int BWD_OFF_LSE = 2 * BWD_STAGE;          // [2][64] lse*log2e, [2][64] delta
-constexpr int BWD_OFF_DS = BWD_OFF_LSE + 1024;      // dS image  [64 q][256 keys] bf16 (512-B rows)
+// LDS map, NB = blocks of 64 head-dim columns: 2 stages x (Qs | dOs | QTs | dOTs, NB x 8 KB each), then
+// [2][64] lse*log2e and [2][64] delta, then (DQ variant, NB = 1) the dS and K^T images
+constexpr int bwd_stage(int nb) { return 32768 * nb; }
+constexpr int bwd_off_lse(int nb) { return 2 * bwd_stage(nb); }
+constexpr int BWD_OFF_DS = bwd_off_lse(1) + 1024;   // dS image  [64 q][256 keys] bf16 (512-B rows)
 constexpr int BWD_OFF_KT = BWD_OFF_DS + 32768;      // K^T image [64 d][256 keys] bf16 (512-B rows)
 constexpr int BWD_LDS = BWD_OFF_KT + 32768;
+constexpr int bwd_lds_kv(int nb) { return bwd_off_lse(nb) + 1024; }
 
 // 512-byte rows (256 bf16): 16-B chunk c of row r lives at chunk c ^ (r & 15) -> the 16x16x32 fragment reads
 // (16 lanes = 16 consecutive rows, same chunk) hit 16 distinct slots of the 256-B bank row.
@@ -247,10 +283,14 @@ __device__ __forceinline__ int off512(int row, int chunk) { return row * 512 + (
 // only dK / dV for its keys (no dS image, no K^T image: 65 KB of LDS, two workgroups per CU); dQ comes from
 // attn_bwd_dq_mfma.  The key blocks of a head sit next to each other in an XCD-aware 1-D grid (they read the same Q / dO).
 // BIAS (key-block variant only): the lane's key bias / scale is the initial value of the S accumulator.
-template <bool DQ, bool BIAS>
+template <bool DQ, bool BIAS, int DH>
 __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
   static_assert(!(DQ && BIAS), "a key bias runs through the key-block variant");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  static_assert(!DQ || DH == 64, "the one-kernel variant is the head-dim-64 case");
+  using G = HeadGeom<DH>;
+  constexpr int NB = G::NB, NKS = G::NKS, NDT = G::NDT;
+  constexpr int BWD_STAGE = bwd_stage(NB), BWD_OFF_LSE = bwd_off_lse(NB);
+  char* const smem = dyn_smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   int bh, kblk = 0;
@@ -268,11 +308,11 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
   const int k0 = kblk * 256 + wave * 32;
   const bool active = k0 < a.Tk;  // wave-uniform
   const bool kvalid = k0 + r < a.Tk;  // this lane's key exists (ragged last block of cross-attention)
-  const bf16_t* qb = a.q + (int64_t)b * a.T * a.ldq + hd * 64;
-  const bf16_t* kb = a.k + (int64_t)b * a.Tk * a.ldk + hd * 64;
-  const bf16_t* vb = a.v + (int64_t)b * a.Tk * a.ldv + hd * 64;
-  const bf16_t* gb = a.dO + (int64_t)b * a.T * a.ldo + hd * 64;
-  const bf16_t* ob = a.o + (int64_t)b * a.T * a.ldo + hd * 64;
+  const bf16_t* qb = a.q + (int64_t)b * a.T * a.ldq + hd * DH;
+  const bf16_t* kb = a.k + (int64_t)b * a.Tk * a.ldk + hd * DH;
+  const bf16_t* vb = a.v + (int64_t)b * a.Tk * a.ldv + hd * DH;
+  const bf16_t* gb = a.dO + (int64_t)b * a.T * a.ldo + hd * DH;
+  const bf16_t* ob = a.o + (int64_t)b * a.T * a.ldo + hd * DH;
   const float* lseb = a.lse + ((int64_t)b * a.H + hd) * a.T;
   const float c = a.scale * 1.4426950408889634f;
   char* dsimg = smem + BWD_OFF_DS;
@@ -302,17 +342,18 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
   }
 
   // per-wave static operands: K and V rows of this wave's 32 keys (B operands of S and dP)
-  uint4 kf[4], vf[4];
+  uint4 kf[NKS], vf[NKS];
   if (active) {
     const int krow = kvalid ? k0 + r : a.Tk - 1;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      kf[s] = *reinterpret_cast<const uint4*>(kb + (int64_t)krow * a.ldk + 16 * s + 8 * h);
-      vf[s] = *reinterpret_cast<const uint4*>(vb + (int64_t)krow * a.ldv + 16 * s + 8 * h);
+    for (int s = 0; s < NKS; ++s) {
+      kf[s] = load16_or_zero(kb + (int64_t)krow * a.ldk + 16 * s + 8 * h, 16 * s + 8 * h < DH);
+      vf[s] = load16_or_zero(vb + (int64_t)krow * a.ldv + 16 * s + 8 * h, 16 * s + 8 * h < DH);
     }
   }
-  f32x16 dkT[2], dvT[2];
-  dkT[0] = dkT[1] = dvT[0] = dvT[1] = f32x16{};
+  f32x16 dkT[NDT], dvT[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) dkT[dt] = dvT[dt] = f32x16{};
   float kbr = 0.f;
   if constexpr (BIAS)
     if (active) kbr = a.kbias[(int64_t)b * a.Tk + (kvalid ? k0 + r : a.Tk - 1)] / a.scale;
@@ -320,30 +361,39 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
   // staging registers: row-major Q and dO (one 16-B chunk each), transposed Q (threads 0-255) or dO (256-511)
   // delta[q] = sum_d dO[q][d] * O[q][d] is computed here from the staged dO chunk and the matching O chunk (8 lanes
   // per row, three shuffles) instead of by a separate pass over O and dO
-  uint4 qreg, greg, oreg;
-  TStage treg;
+  uint4 qreg[NB], greg[NB], oreg[NB];
+  TStage treg[NB];
   float lreg = 0.f;
   auto load_tile = [&](int q0) {
     const int row = tid >> 3, ch = tid & 7;
-    qreg = *reinterpret_cast<const uint4*>(qb + (int64_t)(q0 + row) * a.ldq + 8 * ch);
-    greg = *reinterpret_cast<const uint4*>(gb + (int64_t)(q0 + row) * a.ldo + 8 * ch);
-    oreg = *reinterpret_cast<const uint4*>(ob + (int64_t)(q0 + row) * a.ldo + 8 * ch);
-    if (tid < 256) treg.load(qb, a.ldq, q0, tid); else treg.load(gb, a.ldo, q0, tid - 256);
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+      const int col = 64 * blk + 8 * ch;
+      qreg[blk] = load16_or_zero(qb + (int64_t)(q0 + row) * a.ldq + col, col < DH);
+      greg[blk] = load16_or_zero(gb + (int64_t)(q0 + row) * a.ldo + col, col < DH);
+      oreg[blk] = load16_or_zero(ob + (int64_t)(q0 + row) * a.ldo + col, col < DH);
+      if (tid < 256) treg[blk].load(qb + 64 * blk, a.ldq, q0, tid, 0x7fffffff, DH - 64 * blk);
+      else treg[blk].load(gb + 64 * blk, a.ldo, q0, tid - 256, 0x7fffffff, DH - 64 * blk);
+    }
     if (tid < 64) lreg = lseb[q0 + tid] * 1.4426950408889634f;
   };
   auto store_tile = [&](int stage) {
     char* st = smem + stage * BWD_STAGE;
     const int row = tid >> 3, ch = tid & 7;
-    *reinterpret_cast<uint4*>(st + swz(row, ch)) = qreg;
-    *reinterpret_cast<uint4*>(st + 8192 + swz(row, ch)) = greg;
-    if (tid < 256) treg.store(st + 16384, tid); else treg.store(st + 24576, tid - 256);
+    float ds = 0.f;
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+      *reinterpret_cast<uint4*>(st + blk * 8192 + swz(row, ch)) = qreg[blk];
+      *reinterpret_cast<uint4*>(st + (NB + blk) * 8192 + swz(row, ch)) = greg[blk];
+      if (tid < 256) treg[blk].store(st + (2 * NB + blk) * 8192, tid);
+      else treg[blk].store(st + (3 * NB + blk) * 8192, tid - 256);
+      const bf16x8 gv = *reinterpret_cast<const bf16x8*>(&greg[blk]), ov = *reinterpret_cast<const bf16x8*>(&oreg[blk]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ds += (float)gv[j] * (float)ov[j];
+    }
     float* ls = reinterpret_cast<float*>(smem + BWD_OFF_LSE) + stage * 64;
     float* dl = reinterpret_cast<float*>(smem + BWD_OFF_LSE + 512) + stage * 64;
     if (tid < 64) ls[tid] = lreg;
-    const bf16x8 gv = *reinterpret_cast<const bf16x8*>(&greg), ov = *reinterpret_cast<const bf16x8*>(&oreg);
-    float ds = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ds += (float)gv[j] * (float)ov[j];
     ds += __shfl_xor(ds, 1, 64);
     ds += __shfl_xor(ds, 2, 64);
     ds += __shfl_xor(ds, 4, 64);
@@ -359,9 +409,9 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
   for (int t = 0; t < nt; ++t) {
     const int stage = t & 1;
     const char* Qs = smem + stage * BWD_STAGE;
-    const char* Gs = Qs + 8192;
-    const char* QTs = Qs + 16384;
-    const char* GTs = Qs + 24576;
+    const char* Gs = Qs + NB * 8192;
+    const char* QTs = Qs + 2 * NB * 8192;
+    const char* GTs = Qs + 3 * NB * 8192;
     const float* ls = reinterpret_cast<const float*>(smem + BWD_OFF_LSE) + stage * 64;
     const float* dl = reinterpret_cast<const float*>(smem + BWD_OFF_LSE + 512) + stage * 64;
     if (t + 1 < nt) load_tile((t + 1) * 64);
@@ -375,9 +425,9 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
           for (int i = 0; i < 16; ++i) S[i] = kbr;
         }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          uint4 qa = *reinterpret_cast<const uint4*>(Qs + swz(32 * sub + r, 2 * s + h));
-          uint4 ga = *reinterpret_cast<const uint4*>(Gs + swz(32 * sub + r, 2 * s + h));
+        for (int s = 0; s < NKS; ++s) {
+          uint4 qa = *reinterpret_cast<const uint4*>(Qs + (s >> 2) * 8192 + swz(32 * sub + r, 2 * (s & 3) + h));
+          uint4 ga = *reinterpret_cast<const uint4*>(Gs + (s >> 2) * 8192 + swz(32 * sub + r, 2 * (s & 3) + h));
           S = mfma32(qa, kf[s], S);
           dP = mfma32(ga, vf[s], dP);
         }
@@ -417,9 +467,10 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
           dsf.z = *reinterpret_cast<const unsigned*>(&dsp[4 * s2 + 2]);
           dsf.w = *reinterpret_cast<const unsigned*>(&dsp[4 * s2 + 3]);
 #pragma unroll
-          for (int dt = 0; dt < 2; ++dt) {
-            uint4 gt = *reinterpret_cast<const uint4*>(GTs + swz(32 * dt + r, 2 * (2 * sub + s2) + h));
-            uint4 qt = *reinterpret_cast<const uint4*>(QTs + swz(32 * dt + r, 2 * (2 * sub + s2) + h));
+          for (int dt = 0; dt < NDT; ++dt) {
+            const int off = (dt >> 1) * 8192 + swz(32 * (dt & 1) + r, 2 * (2 * sub + s2) + h);
+            uint4 gt = *reinterpret_cast<const uint4*>(GTs + off);
+            uint4 qt = *reinterpret_cast<const uint4*>(QTs + off);
             dvT[dt] = mfma32(gt, pf, dvT[dt]);
             dkT[dt] = mfma32(qt, dsf, dkT[dt]);
           }
@@ -449,13 +500,14 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
     __syncthreads();  // dS image free again; next stage visible
   }
   if (active && kvalid) {
-    bf16_t* dkb = a.dk + (int64_t)b * a.Tk * a.ldk + hd * 64 + (int64_t)(k0 + r) * a.ldk;
-    bf16_t* dvb = a.dv + (int64_t)b * a.Tk * a.ldv + hd * 64 + (int64_t)(k0 + r) * a.ldv;
+    bf16_t* dkb = a.dk + (int64_t)b * a.Tk * a.ldk + hd * DH + (int64_t)(k0 + r) * a.ldk;
+    bf16_t* dvb = a.dv + (int64_t)b * a.Tk * a.ldv + hd * DH + (int64_t)(k0 + r) * a.ldv;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const int d0 = 32 * dt + 8 * g4 + 4 * h;
+        if (DH % 32 != 0 && d0 >= DH) continue;
         store4(dkb + d0, f32x4{dkT[dt][4 * g4] * a.scale, dkT[dt][4 * g4 + 1] * a.scale,
                                dkT[dt][4 * g4 + 2] * a.scale, dkT[dt][4 * g4 + 3] * a.scale});
         store4(dvb + d0, f32x4{dvT[dt][4 * g4], dvT[dt][4 * g4 + 1], dvT[dt][4 * g4 + 2], dvT[dt][4 * g4 + 3]});
@@ -471,10 +523,14 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
 //   dQ^T[d][q] += K^T[d][key] . dS^T[key][q]              (dS^T accumulator reused as the B operand, as P^T in forward)
 // so dQ accumulates over all key tiles in the wave's own registers: no atomics, no cross-workgroup reduction.
 // delta[q] = sum_d dO O is formed from the wave's own dO fragments and the matching O chunks.
-template <bool BIAS>
+template <bool BIAS, int DH>
 __global__ void __launch_bounds__(256, 2) attn_bwd_dq_mfma(const MArgs a) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * 24576];  // 2 stages x (K 8 KB | V 8 KB | K^T 8 KB)
+  using G = HeadGeom<DH>;
+  constexpr int NB = G::NB, NKS = G::NKS, NDT = G::NDT;
+  constexpr int STAGE = 3 * NB * 8192;  // K blocks | V blocks | K^T blocks
+  __shared__ __attribute__((aligned(16))) char st_smem[NB == 1 ? 2 * STAGE : 16];
   __shared__ __attribute__((aligned(16))) float kbs[BIAS ? 128 : 4];
+  char* const smem = NB == 1 ? st_smem : dyn_smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int ntq = (a.T + 127) / 128, total = ntq * a.B * a.H;
@@ -487,21 +543,22 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_mfma(const MArgs a) {
   const int bh = lid / ntq, b = bh / a.H, hd = bh - b * a.H;
   const int q0 = (lid - bh * ntq) * 128 + wave * 32;
   const bool active = q0 < a.T;  // wave-uniform
-  const bf16_t* qb = a.q + (int64_t)b * a.T * a.ldq + hd * 64;
-  const bf16_t* kb = a.k + (int64_t)b * a.Tk * a.ldk + hd * 64;
-  const bf16_t* vb = a.v + (int64_t)b * a.Tk * a.ldv + hd * 64;
-  const bf16_t* gb = a.dO + (int64_t)b * a.T * a.ldo + hd * 64;
-  const bf16_t* ob = a.o + (int64_t)b * a.T * a.ldo + hd * 64;
+  const bf16_t* qb = a.q + (int64_t)b * a.T * a.ldq + hd * DH;
+  const bf16_t* kb = a.k + (int64_t)b * a.Tk * a.ldk + hd * DH;
+  const bf16_t* vb = a.v + (int64_t)b * a.Tk * a.ldv + hd * DH;
+  const bf16_t* gb = a.dO + (int64_t)b * a.T * a.ldo + hd * DH;
+  const bf16_t* ob = a.o + (int64_t)b * a.T * a.ldo + hd * DH;
   const float c = a.scale * 1.4426950408889634f;
 
-  uint4 qf[4], gf[4];
+  uint4 qf[NKS], gf[NKS];
   float lq = 0.f, dl = 0.f;
   if (active) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      qf[s] = *reinterpret_cast<const uint4*>(qb + (int64_t)(q0 + r) * a.ldq + 16 * s + 8 * h);
-      gf[s] = *reinterpret_cast<const uint4*>(gb + (int64_t)(q0 + r) * a.ldo + 16 * s + 8 * h);
-      const uint4 of = *reinterpret_cast<const uint4*>(ob + (int64_t)(q0 + r) * a.ldo + 16 * s + 8 * h);
+    for (int s = 0; s < NKS; ++s) {
+      const bool ok = 16 * s + 8 * h < DH;
+      qf[s] = load16_or_zero(qb + (int64_t)(q0 + r) * a.ldq + 16 * s + 8 * h, ok);
+      gf[s] = load16_or_zero(gb + (int64_t)(q0 + r) * a.ldo + 16 * s + 8 * h, ok);
+      const uint4 of = load16_or_zero(ob + (int64_t)(q0 + r) * a.ldo + 16 * s + 8 * h, ok);
       const bf16x8 gv = *reinterpret_cast<const bf16x8*>(&gf[s]), ov = *reinterpret_cast<const bf16x8*>(&of);
 #pragma unroll
       for (int j = 0; j < 8; ++j) dl += (float)gv[j] * (float)ov[j];
@@ -509,33 +566,41 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_mfma(const MArgs a) {
     dl += __shfl_xor(dl, 32, 64);  // the two lane halves hold the two halves of the row
     lq = a.lse[((int64_t)b * a.H + hd) * a.T + q0 + r] * 1.4426950408889634f;
   }
-  f32x16 dq[2];
-  dq[0] = dq[1] = f32x16{};
+  f32x16 dq[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) dq[dt] = f32x16{};
 
-  uint4 kreg[2], vreg[2];
-  TStage ktreg;
+  uint4 kreg[NB][2], vreg[NB][2];
+  TStage ktreg[NB];
   float kbreg = 0.f;
   const float inv_scale = 1.f / a.scale;
   auto load_tile = [&](int k0) {
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      int row = k0 + (tid >> 3) + 32 * p;
-      if (row >= a.Tk) row = a.Tk - 1;  // keys past Tk: clamped, their dS is zeroed below
-      kreg[p] = *reinterpret_cast<const uint4*>(kb + (int64_t)row * a.ldk + 8 * (tid & 7));
-      vreg[p] = *reinterpret_cast<const uint4*>(vb + (int64_t)row * a.ldv + 8 * (tid & 7));
+    for (int blk = 0; blk < NB; ++blk) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        int row = k0 + (tid >> 3) + 32 * p;
+        if (row >= a.Tk) row = a.Tk - 1;  // keys past Tk: clamped, their dS is zeroed below
+        const int col = 64 * blk + 8 * (tid & 7);
+        kreg[blk][p] = load16_or_zero(kb + (int64_t)row * a.ldk + col, col < DH);
+        vreg[blk][p] = load16_or_zero(vb + (int64_t)row * a.ldv + col, col < DH);
+      }
+      ktreg[blk].load(kb + 64 * blk, a.ldk, k0, tid, a.Tk, DH - 64 * blk);
     }
-    ktreg.load(kb, a.ldk, k0, tid, a.Tk);
     if constexpr (BIAS)
       if (tid < 64) kbreg = a.kbias[(int64_t)b * a.Tk + min(k0 + tid, a.Tk - 1)] * inv_scale;
   };
   auto store_tile = [&](int stage) {
-    char* st = smem + stage * 24576;
+    char* st = smem + stage * STAGE;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      *reinterpret_cast<uint4*>(st + swz((tid >> 3) + 32 * p, tid & 7)) = kreg[p];
-      *reinterpret_cast<uint4*>(st + 8192 + swz((tid >> 3) + 32 * p, tid & 7)) = vreg[p];
+    for (int blk = 0; blk < NB; ++blk) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        *reinterpret_cast<uint4*>(st + blk * 8192 + swz((tid >> 3) + 32 * p, tid & 7)) = kreg[blk][p];
+        *reinterpret_cast<uint4*>(st + (NB + blk) * 8192 + swz((tid >> 3) + 32 * p, tid & 7)) = vreg[blk][p];
+      }
+      ktreg[blk].store(st + (2 * NB + blk) * 8192, tid);
     }
-    ktreg.store(st + 16384, tid);
     if constexpr (BIAS)
       if (tid < 64) kbs[stage * 64 + tid] = kbreg;
   };
@@ -545,9 +610,9 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_mfma(const MArgs a) {
   store_tile(0);
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
-    const char* Ks = smem + (t & 1) * 24576;
-    const char* Vs = Ks + 8192;
-    const char* KTs = Ks + 16384;
+    const char* Ks = smem + (t & 1) * STAGE;
+    const char* Vs = Ks + NB * 8192;
+    const char* KTs = Ks + 2 * NB * 8192;
     if (t + 1 < nt) load_tile((t + 1) * 64);
     if (active) {
       f32x16 s[2], dp[2];
@@ -564,9 +629,10 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_mfma(const MArgs a) {
           }
         }
 #pragma unroll
-        for (int ss = 0; ss < 4; ++ss) {
-          const uint4 kf = *reinterpret_cast<const uint4*>(Ks + swz(32 * kt + r, 2 * ss + h));
-          const uint4 vf = *reinterpret_cast<const uint4*>(Vs + swz(32 * kt + r, 2 * ss + h));
+        for (int ss = 0; ss < NKS; ++ss) {
+          const int off = (ss >> 2) * 8192 + swz(32 * kt + r, 2 * (ss & 3) + h);
+          const uint4 kf = *reinterpret_cast<const uint4*>(Ks + off);
+          const uint4 vf = *reinterpret_cast<const uint4*>(Vs + off);
           s[kt] = mfma32(kf, qf[ss], s[kt]);
           dp[kt] = mfma32(vf, gf[ss], dp[kt]);
         }
@@ -591,8 +657,9 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_mfma(const MArgs a) {
         for (int s2 = 0; s2 < 2; ++s2) {
           const uint4 dsf = pack8(s[kt], s2);
 #pragma unroll
-          for (int dt = 0; dt < 2; ++dt) {
-            const uint4 ktf = *reinterpret_cast<const uint4*>(KTs + swz(32 * dt + r, 2 * (2 * kt + s2) + h));
+          for (int dt = 0; dt < NDT; ++dt) {
+            const uint4 ktf = *reinterpret_cast<const uint4*>(KTs + (dt >> 1) * 8192 +
+                                                              swz(32 * (dt & 1) + r, 2 * (2 * kt + s2) + h));
             dq[dt] = mfma32(ktf, dsf, dq[dt]);
           }
         }
@@ -601,12 +668,13 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_mfma(const MArgs a) {
     __syncthreads();
   }
   if (active) {
-    bf16_t* dqb = a.dq + (int64_t)b * a.T * a.ldq + hd * 64 + (int64_t)(q0 + r) * a.ldq;
+    bf16_t* dqb = a.dq + (int64_t)b * a.T * a.ldq + hd * DH + (int64_t)(q0 + r) * a.ldq;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const int d0 = 32 * dt + 8 * g4 + 4 * h;
+        if (DH % 32 != 0 && d0 >= DH) continue;
         store4(dqb + d0, f32x4{dq[dt][4 * g4] * a.scale, dq[dt][4 * g4 + 1] * a.scale, dq[dt][4 * g4 + 2] * a.scale,
                                dq[dt][4 * g4 + 3] * a.scale});
       }
@@ -616,62 +684,104 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_mfma(const MArgs a) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------- host side
-// head dim 64, whole 64-row query tiles; any number of keys (ragged key tiles are masked: cross-attention, Tk = 77)
+// head dim 64 / 72 / 128, whole 64-row query tiles; any number of keys (ragged key tiles are masked: cross-attention,
+// Tk = 77)
 bool uwu_attn_mfma_fwd_ok(int Tq, int Tk, int d, int ldq, int ldk, int ldv, int ldo) {
-  return d == 64 && Tk >= 1 && Tq % 64 == 0 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0;
+  return (d == 64 || d == 72 || d == 128) && Tk >= 1 && Tq % 64 == 0 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 &&
+         ldo % 8 == 0;
 }
 bool uwu_attn_mfma_bwd_ok(int Tq, int Tk, int d, int ldq, int ldk, int ldv, int ldo) {
   return uwu_attn_mfma_fwd_ok(Tq, Tk, d, ldq, ldk, ldv, ldo);
 }
 
+namespace {
+
+template <typename K>
+void allow_lds(K kernel, int bytes) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+template <int DH>
+void launch_fwd(const MArgs& a, hipStream_t st) {
+  constexpr int NB = HeadGeom<DH>::NB;
+  constexpr int lds = NB == 1 ? 0 : 2 * 2 * NB * 8192;  // wider heads: the two stages live in dynamic LDS
+  static bool once = false;
+  if (!once && lds) {
+    allow_lds(attn_fwd_mfma<true, DH>, lds);
+    allow_lds(attn_fwd_mfma<false, DH>, lds);
+  }
+  once = true;
+  const dim3 grid(((a.T + 127) / 128) * a.B * a.H);
+  if (a.kbias) hipLaunchKernelGGL((attn_fwd_mfma<true, DH>), grid, dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((attn_fwd_mfma<false, DH>), grid, dim3(256), lds, st, a);
+}
+
+template <int DH>
+void launch_bwd(const MArgs& a, hipStream_t st) {
+  constexpr int NB = HeadGeom<DH>::NB;
+  constexpr int lds_kv = bwd_lds_kv(NB);                  // key-block variant: the two staging stages + lse / delta
+  constexpr int lds_dq = NB == 1 ? 0 : 2 * 3 * NB * 8192;
+  static bool once = false;
+  if (!once) {
+    if constexpr (DH == 64) allow_lds(attn_bwd_mfma<true, false, 64>, BWD_LDS);
+    allow_lds(attn_bwd_mfma<false, false, DH>, lds_kv);
+    allow_lds(attn_bwd_mfma<false, true, DH>, lds_kv);
+    if (lds_dq) {
+      allow_lds(attn_bwd_dq_mfma<true, DH>, lds_dq);
+      allow_lds(attn_bwd_dq_mfma<false, DH>, lds_dq);
+    }
+  }
+  once = true;
+  const dim3 gkv(a.B * a.H * ((a.Tk + 255) / 256)), gq(a.B * a.H * ((a.T + 127) / 128));
+  if (a.kbias) {  // biased scores: always the two-kernel form
+    hipLaunchKernelGGL((attn_bwd_mfma<false, true, DH>), gkv, dim3(512), lds_kv, st, a);
+    hipLaunchKernelGGL((attn_bwd_dq_mfma<true, DH>), gq, dim3(256), lds_dq, st, a);
+    return;
+  }
+  if constexpr (DH == 64) {
+    if (a.T == a.Tk && a.T <= 256) {
+      hipLaunchKernelGGL((attn_bwd_mfma<true, false, 64>), dim3(a.B * a.H), dim3(512), BWD_LDS, st, a);
+      return;
+    }
+  }
+  // dK / dV per block of 256 keys, dQ per tile of 128 queries
+  hipLaunchKernelGGL((attn_bwd_mfma<false, false, DH>), gkv, dim3(512), lds_kv, st, a);
+  hipLaunchKernelGGL((attn_bwd_dq_mfma<false, DH>), gq, dim3(256), lds_dq, st, a);
+}
+
+}  // namespace
+
 int uwu_attn_mfma_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* kbias, int B,
-                      int T, int Tk, int H, int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t st) {
+                      int T, int Tk, int H, int d, int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t st) {
   UWU_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0,
                 "attention(mfma): q/k/v/o must be 16-byte aligned");
   MArgs a{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)o; a.lse = lse;
   a.kbias = kbias;
   a.B = B; a.T = T; a.Tk = Tk; a.H = H; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.scale = scale;
-  if (kbias) hipLaunchKernelGGL(attn_fwd_mfma<true>, dim3(((T + 127) / 128) * B * H), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(attn_fwd_mfma<false>, dim3(((T + 127) / 128) * B * H), dim3(256), 0, st, a);
+  if (d == 64) launch_fwd<64>(a, st);
+  else if (d == 72) launch_fwd<72>(a, st);
+  else launch_fwd<128>(a, st);
   UWU_LAUNCH_CHECK("attention_fwd(mfma)");
   return UWU_OK;
 }
 
 int uwu_attn_mfma_bwd(const void* q, const void* k, const void* v, const void* o, const void* dO, const float* lse,
                       float* delta, const float* kbias, void* dq, void* dk, void* dv, int B, int T, int Tk, int H,
-                      int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t st) {
+                      int d, int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t st) {
   UWU_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)dO | (uintptr_t)dq |
                   (uintptr_t)dk | (uintptr_t)dv) & 15) == 0,
                 "attention_bwd(mfma): tensors must be 16-byte aligned");
-  constexpr int LDS_KV = BWD_OFF_LSE + 1024;  // key-block variant: the two staging stages + lse / delta
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma<true, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma<false, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_KV);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma<false, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_KV);
-    attr_done = true;
-  }
-  (void)delta;  // the row sums of dO * O are formed inside the kernel
+  (void)delta;  // the row sums of dO * O are formed inside the kernels
   MArgs a{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o;
   a.dO = (const bf16_t*)dO; a.lse = const_cast<float*>(lse); a.delta = delta;
   a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
   a.kbias = kbias;
   a.B = B; a.T = T; a.Tk = Tk; a.H = H; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.scale = scale;
-  const dim3 gkv(B * H * ((Tk + 255) / 256)), gq(B * H * ((T + 127) / 128));
-  if (kbias) {  // biased scores: always the two-kernel form
-    hipLaunchKernelGGL((attn_bwd_mfma<false, true>), gkv, dim3(512), LDS_KV, st, a);
-    hipLaunchKernelGGL(attn_bwd_dq_mfma<true>, gq, dim3(256), 0, st, a);
-  } else if (T == Tk && T <= 256) {
-    hipLaunchKernelGGL((attn_bwd_mfma<true, false>), dim3(B * H), dim3(512), BWD_LDS, st, a);
-  } else {  // dK / dV per block of 256 keys, dQ per tile of 128 queries
-    hipLaunchKernelGGL((attn_bwd_mfma<false, false>), gkv, dim3(512), LDS_KV, st, a);
-    hipLaunchKernelGGL(attn_bwd_dq_mfma<false>, gq, dim3(256), 0, st, a);
-  }
+  if (d == 64) launch_bwd<64>(a, st);
+  else if (d == 72) launch_bwd<72>(a, st);
+  else launch_bwd<128>(a, st);
   UWU_LAUNCH_CHECK("attention_bwd(mfma)");
   return UWU_OK;
 }

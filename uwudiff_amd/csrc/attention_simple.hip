@@ -1,7 +1,7 @@
 // Generic-dtype scaled-dot-product attention (forward + backward), VALU only.
 //
 // This is the exact-fp32 parity path (and the fallback for shapes the MFMA kernel in attention_mfma.hip does
-// not cover: ragged Tk such as the 77 text tokens of cross-attention, odd head sizes).  Two lanes share one
+// not cover: query counts that are not multiples of 64, head dim 32, fp32 operands).  Two lanes share one
 // row (each owns half of the head dimension, partial dot products are exchanged with one DPP/shuffle), K/V (or
 // Q/dO) tiles of 32 rows are staged in LDS as fp32 and read as wave-broadcasts.
 // Semantics: F.scaled_dot_product_attention(q,k,v, dropout_p=0, is_causal=False) -- reference
@@ -290,9 +290,8 @@ int by_head(const AttnArgs& a, bool bwd, hipStream_t st) {
     case 32: return bwd ? run_bwd<T, 32>(a, st) : run_fwd<T, 32>(a, st);
     case 64: return bwd ? run_bwd<T, 64>(a, st) : run_fwd<T, 64>(a, st);
     case 72: return bwd ? run_bwd<T, 72>(a, st) : run_fwd<T, 72>(a, st);
-    case 128: return bwd ? run_bwd<T, 128>(a, st) : run_fwd<T, 128>(a, st);
     default:
-      uwu_set_error("attention: head dim %d not instantiated (32, 64, 72, 128)", a.d);
+      uwu_set_error("attention: head dim %d not instantiated in the generic kernels (32, 64, 72)", a.d);
       return UWU_EINVAL;
   }
 }
@@ -310,10 +309,10 @@ static int uwu_attention_simple(const AttnArgs& a, int dtype, bool bwd, hipStrea
 bool uwu_attn_mfma_fwd_ok(int Tq, int Tk, int d, int ldq, int ldk, int ldv, int ldo);
 bool uwu_attn_mfma_bwd_ok(int Tq, int Tk, int d, int ldq, int ldk, int ldv, int ldo);
 int uwu_attn_mfma_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* kbias, int B,
-                      int T, int Tk, int H, int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t st);
+                      int T, int Tk, int H, int d, int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t st);
 int uwu_attn_mfma_bwd(const void* q, const void* k, const void* v, const void* o, const void* dO, const float* lse,
                       float* delta, const float* kbias, void* dq, void* dk, void* dv, int B, int T, int Tk, int H,
-                      int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t st);
+                      int d, int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t st);
 static bool force_simple() {
   static int v = -1;
   if (v < 0) {
@@ -345,7 +344,7 @@ static int attention_fwd_impl(const void* q, const void* k, const void* v, void*
   UWU_CHECK_ARG(scale > 0.f, "attention: scale must be positive");
   if (dtype == UWU_BF16 && !force_simple() && uwu_attn_mfma_fwd_ok(Tq, Tk, d, ldq, ldk, ldv, ldo) &&
       (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0)
-    return uwu_attn_mfma_fwd(q, k, v, o, lse, kbias, B, Tq, Tk, H, ldq, ldk, ldv, ldo, scale, (hipStream_t)stream);
+    return uwu_attn_mfma_fwd(q, k, v, o, lse, kbias, B, Tq, Tk, H, d, ldq, ldk, ldv, ldo, scale, (hipStream_t)stream);
   AttnArgs a{};
   a.q = q; a.k = k; a.v = v; a.out = o; a.lse = lse; a.kbias = kbias;
   a.B = B; a.Tq = Tq; a.Tk = Tk; a.H = H; a.d = d; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
@@ -364,7 +363,7 @@ static int attention_bwd_impl(const void* q, const void* k, const void* v, const
   if (dtype == UWU_BF16 && !force_simple() && uwu_attn_mfma_bwd_ok(Tq, Tk, d, ldq, ldk, ldv, ldo) &&
       (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)dO | (uintptr_t)dq | (uintptr_t)dk |
         (uintptr_t)dv) & 15) == 0)
-    return uwu_attn_mfma_bwd(q, k, v, o, dO, lse, delta, kbias, dq, dk, dv, B, Tq, Tk, H, ldq, ldk, ldv, ldo, scale,
+    return uwu_attn_mfma_bwd(q, k, v, o, dO, lse, delta, kbias, dq, dk, dv, B, Tq, Tk, H, d, ldq, ldk, ldv, ldo, scale,
                              (hipStream_t)stream);
   AttnArgs a{};
   a.q = q; a.k = k; a.v = v; a.o = o; a.dO = dO; a.lse = const_cast<float*>(lse); a.delta = delta; a.dq = dq; a.dk = dk; a.dv = dv;
