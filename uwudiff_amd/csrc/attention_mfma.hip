@@ -18,7 +18,7 @@
 //   exchange -> P^T stays in registers as the B operand of  O^T[d][q] += V^T[d][key].P^T[key][q].
 // backward (8 waves x 32 keys, whole key range <= 256 in one workgroup, query tiles of 64 rows):
 //   S[q][key] = Q.K^T, dP[q][key] = dO.V^T   (key on the lane; K/V fragments in registers)
-//   P = exp2(c*S - lse), dS = P*(dP - delta)
+//   P = exp2(c*S'), dS = P*dP' with S' = S - lse/scale and dP' = dP - delta formed by the accumulators' initial values
 //   dV^T[d][key] += dO^T[d][q].P[q][key],  dK^T[d][key] += Q^T[d][q].dS[q][key]   (accumulators as B operands)
 //   dQ contracts over the key = the LANE index of dS, so dS takes the one trip through LDS: every wave writes
 //   its 32-key slice into a shared [q][key] bf16 image, then each wave computes two 16x16 blocks of
@@ -357,6 +357,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
   float kbr = 0.f;
   if constexpr (BIAS)
     if (active) kbr = a.kbias[(int64_t)b * a.Tk + (kvalid ? k0 + r : a.Tk - 1)] / a.scale;
+  (void)kbr;
 
   // staging registers: row-major Q and dO (one 16-B chunk each), transposed Q (threads 0-255) or dO (256-511)
   // delta[q] = sum_d dO[q][d] * O[q][d] is computed here from the staged dO chunk and the matching O chunk (8 lanes
@@ -364,6 +365,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
   uint4 qreg[NB], greg[NB], oreg[NB];
   TStage treg[NB];
   float lreg = 0.f;
+  const float inv_scale = 1.f / a.scale;
   auto load_tile = [&](int q0) {
     const int row = tid >> 3, ch = tid & 7;
 #pragma unroll
@@ -375,7 +377,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
       if (tid < 256) treg[blk].load(qb + 64 * blk, a.ldq, q0, tid, 0x7fffffff, DH - 64 * blk);
       else treg[blk].load(gb + 64 * blk, a.ldo, q0, tid - 256, 0x7fffffff, DH - 64 * blk);
     }
-    if (tid < 64) lreg = lseb[q0 + tid] * 1.4426950408889634f;
+    if (tid < 64) lreg = -lseb[q0 + tid] * inv_scale;  // row constant of S, in units of the raw dot product
   };
   auto store_tile = [&](int stage) {
     char* st = smem + stage * BWD_STAGE;
@@ -397,7 +399,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
     ds += __shfl_xor(ds, 1, 64);
     ds += __shfl_xor(ds, 2, 64);
     ds += __shfl_xor(ds, 4, 64);
-    if (ch == 0) dl[row] = ds;
+    if (ch == 0) dl[row] = -ds;
   };
 
   const int nt = a.T / 64;
@@ -419,10 +421,18 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
     if (active) {
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
-        f32x16 S = {}, dP = {};
-        if constexpr (BIAS) {
+        // the row constants -lse / scale and -delta are the INITIAL accumulators of S and dP (one LDS read each, no
+        // subtraction after the chains): p = exp2(c * S'), dS = p * dP'
+        f32x16 S, dP;
 #pragma unroll
-          for (int i = 0; i < 16; ++i) S[i] = kbr;
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x4 l4 = load4(ls + 32 * sub + 8 * g4 + 4 * h);
+          const f32x4 d4 = load4(dl + 32 * sub + 8 * g4 + 4 * h);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            S[4 * g4 + e] = BIAS ? l4[e] + kbr : l4[e];
+            dP[4 * g4 + e] = d4[e];
+          }
         }
 #pragma unroll
         for (int s = 0; s < NKS; ++s) {
@@ -433,17 +443,11 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
         }
         // P and dS in place (rows = q in registers, cols = key on lanes)
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const f32x4 l4 = load4(ls + 32 * sub + 8 * g4 + 4 * h);
-          const f32x4 d4 = load4(dl + 32 * sub + 8 * g4 + 4 * h);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int i = 4 * g4 + e;
-            float p = fexp2(S[i] * c - l4[e]);
-            if constexpr (!DQ) p = kvalid ? p : 0.f;  // (self-attention with T <= 256: every key of an active wave exists)
-            S[i] = p;
-            dP[i] = p * (dP[i] - d4[e]);
-          }
+        for (int i = 0; i < 16; ++i) {
+          float p = fexp2(S[i] * c);
+          if constexpr (!DQ) p = kvalid ? p : 0.f;  // (self-attention with T <= 256: every key of an active wave exists)
+          S[i] = p;
+          dP[i] *= p;
         }
         // dS is rounded to bf16 ONCE (8 packed pairs): the pairs feed both the shared image and the dK operand
         bf16x2 dsp[8];
