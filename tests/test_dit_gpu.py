@@ -55,10 +55,13 @@ def run_pair(cfg, dtype, B, seed=0):
 
 SMALL = dict(depth=2, hidden=128, heads=2, patch=2, sample_size=16, in_channels=4, out_channels=4, cond_dim=0)
 SMALL_COND = dict(SMALL, cond_dim=32, depth=3)
+# DiT-XL's head shape (1152 / 16 = 72) on a small model: T = 256 tokens so the bf16 run takes the MFMA attention kernels
+HEAD72 = dict(depth=2, hidden=144, heads=2, patch=2, sample_size=32, in_channels=4, out_channels=4, cond_dim=32)
 DIT_S = dict(depth=12, hidden=384, heads=6, patch=2, sample_size=32, in_channels=4, out_channels=4, cond_dim=1280)
 
 
-@pytest.mark.parametrize("cfg,B", [(SMALL, 3), (SMALL_COND, 2), (DIT_S, 2)], ids=["small", "small_cond", "dit_s2"])
+@pytest.mark.parametrize("cfg,B", [(SMALL, 3), (SMALL_COND, 2), (DIT_S, 2), (HEAD72, 2)],
+                         ids=["small", "small_cond", "dit_s2", "head72"])
 def test_dit_fp32_matches_oracle(cfg, B):
     y, yo, grads = run_pair(cfg, "fp32", B)
     l2, mx = rel(y, yo)
@@ -70,7 +73,7 @@ def test_dit_fp32_matches_oracle(cfg, B):
         assert l2 < 1e-3 and mx < 1e-3, (name, l2, mx)
 
 
-@pytest.mark.parametrize("cfg,B", [(SMALL_COND, 4), (DIT_S, 2)], ids=["small_cond", "dit_s2"])
+@pytest.mark.parametrize("cfg,B", [(SMALL_COND, 4), (DIT_S, 2), (HEAD72, 3)], ids=["small_cond", "dit_s2", "head72"])
 def test_dit_bf16_close_to_oracle(cfg, B):
     y, yo, grads = run_pair(cfg, "bf16", B)
     l2, _ = rel(y, yo)

@@ -480,6 +480,7 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmArgs g) {
   // ---------------------------------------------------------------- epilogue
   if constexpr (ACC) {
     float* C = static_cast<float*>(g.C);
+    const bool alone = gridDim.z == 1;  // one K slice: this workgroup is the tile's only writer -> plain read-add-write
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -488,7 +489,11 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(const GemmArgs g) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int m = m0 + wm * 64 + 16 * i + 4 * fq + r;
-          if (m < g.M && n < g.N) atomicAdd(C + (int64_t)m * g.ldc + n, acc[i][j][r]);
+          if (m < g.M && n < g.N) {
+            float* c = C + (int64_t)m * g.ldc + n;
+            if (alone) *c += acc[i][j][r];
+            else atomicAdd(c, acc[i][j][r]);
+          }
         }
       }
   } else {
@@ -1195,7 +1200,11 @@ extern "C" int uwu_gemm_wgrad(const void* A, const void* B, float* C, float* bia
   const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
   const int bk = dtype == UWU_BF16 ? 64 : 32;
   int split = (blocks + tiles - 1) / tiles;
-  if (split > (K + bk - 1) / bk) split = (K + bk - 1) / bk;
+  // a slice that adds a whole fp32 tile with atomics has to amortise them over >= 8 K steps (the cross-attention
+  // key / value weights see K = B x 77 tokens: 5 slices of 1-2 steps each took 119 us, one slice of 8 takes 15)
+  const int ksteps = (K + bk - 1) / bk;
+  if (split > ksteps / 8) split = ksteps / 8;
+  if (split < 1) split = 1;
   return uwu_gemm(A, B, C, nullptr, nullptr, nullptr, M, N, K, lda, ldb, ldc, 0, 1, 1, dtype, UWU_F32, UWU_EPI_ACCUM,
                   split, stream);
 }

@@ -241,6 +241,9 @@ extern "C" int uwu_add_ln_modulate_bwd(const void* dh, const void* x, const floa
   int rows = 32;
   while (rows > 1 && T % rows) rows >>= 1;
   const int M = B * T;
+  // small batches: fewer rows per workgroup (down to one per wave) until the grid has ~4 workgroups per CU -- at
+  // M = 4096 the 128 workgroups of 32 rows took 18.5 us, most of it eight dependent row passes per wave
+  while (rows > 4 && M / rows < 1024) rows >>= 1;
   const size_t lds = (size_t)4 * 3 * D * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   UWU_CHECK_ARG(dtype == UWU_F32 || dtype == UWU_BF16, "add_ln_modulate_bwd: bad dtype");
