@@ -173,6 +173,44 @@ def test_gemm_r3_exact_integers_and_dgelu(monkeypatch):
     torch.testing.assert_close(s0, s1, rtol=1e-4, atol=1.0)  # fp32 atomics: order differs
 
 
+def test_gemm_big_tile_matches_128_kernel(monkeypatch):
+    """256x256 kernel (gemm_big_kernel) on the two GELU Linears: same bits as the 128x128 kernel."""
+    from uwudiff_amd import lib as L
+    from uwudiff_amd import ops
+
+    def both(fn):
+        monkeypatch.setenv("UWU_GEMM_R3", "0")
+        monkeypatch.setenv("UWU_GEMM_BIG", "0")
+        ref = fn()
+        monkeypatch.setenv("UWU_GEMM_R3", "1")
+        monkeypatch.setenv("UWU_GEMM_BIG", "1")
+        return ref, fn()
+
+    for M, N, K in [(65536, 1536, 384), (33000, 768, 192)]:
+        a, b = _operands(M, N, K, False, False, torch.bfloat16, ints=False, seed=31)
+        bias = torch.randn(N, generator=torch.Generator().manual_seed(32)).cuda()
+        (u0, f0), (u1, f1) = both(lambda: ops.gemm(a, b, bias=bias, epilogue=L.EPI_BIAS_GELU))
+        assert torch.equal(u0, u1) and torch.equal(f0, f1)
+        for kw in ({}, dict(bias=bias, epilogue=L.EPI_BIAS)):
+            ref, got = both(lambda: ops.gemm(a, b, **kw))
+            assert torch.equal(ref, got)
+        # input gradient with the GELU derivative and the bias-gradient column sums: dy [M, K'] x W [K', N]
+        Kc = K
+        dy, w = _operands(M, N, Kc, False, True, torch.bfloat16, ints=False, seed=33)
+        u = (torch.randn(M, N, generator=torch.Generator().manual_seed(34)) * 1.5).bfloat16().cuda()
+
+        def run():
+            cs = torch.zeros(N, device="cuda")
+            out = ops.gemm(dy, w, trans_b=True, aux=u, epilogue=L.EPI_DGELU, out2=cs)
+            return (out[0] if isinstance(out, tuple) else out), cs
+
+        (d0, s0), (d1, s1) = both(run)
+        assert torch.equal(d0, d1)
+        torch.testing.assert_close(s0, s1, rtol=1e-3, atol=0.5)  # fp32 atomics: order differs
+        ref, got = both(lambda: ops.gemm(dy, w, trans_b=True))
+        assert torch.equal(ref, got)
+
+
 # ---- K-major x K-major accumulate kernel (gemm_tr_kernel: LDS-DMA + ds_read_b64_tr_b16), used for the weight
 # gradients dW += dY^T X with split-K.  Integer operands make every partial sum exact, so the fp32 atomics are
 # order-independent and the result must equal both the exact matmul and the 128x128 kernel (UWU_GEMM_TR=0).

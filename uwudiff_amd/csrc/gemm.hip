@@ -227,7 +227,8 @@ __device__ __forceinline__ void epi_prefetch(EpiPre<T, FI, FJ>& pre, const GemmA
 // cs_lds: >= 4 * 16 * FJ floats of LDS, free once every wave has left the K loop (dGELU column sums only).
 template <typename T, typename TC, int FI, int FJ, int EPI = -1>
 __device__ __forceinline__ void epilogue_tile(f32x4 (&acc)[FI][FJ], EpiPre<T, FI, FJ>& pre, const GemmArgs& g, int m_w,
-                                              int n_w, int fr, int fq, float* cs_lds, int wm, int wn) {
+                                              int n_w, int fr, int fq, float* cs_lds, int wm, int wn, int cs_t = -1) {
+  // cs_t: this thread's index among the flushers of its 2 x 2-wave column group (default: threadIdx.x, one group)
   TC* C = static_cast<TC*>(g.C);
   TC* C2 = static_cast<TC*>(g.C2);
   const int epi = EPI >= 0 ? EPI : g.epi;
@@ -282,7 +283,7 @@ __device__ __forceinline__ void epilogue_tile(f32x4 (&acc)[FI][FJ], EpiPre<T, FI
       if (fr == 0) store4(cs_lds + wm * BNT + wn * 16 * FJ + 16 * j + 4 * fq, v);
     }
     __syncthreads();
-    const int t = threadIdx.x, n = n_w - wn * 16 * FJ + t;
+    const int t = cs_t >= 0 ? cs_t : (int)threadIdx.x, n = n_w - wn * 16 * FJ + t;
     if (t < BNT && n < g.N) atomicAdd(colsum + n, cs_lds[t] + cs_lds[BNT + t]);
   };
   // bf16 output: stores are instruction-bound (fp32 output of the same tile costs the same per store), so
@@ -681,6 +682,119 @@ __global__ void __launch_bounds__(256, 2) gemm_r3_kernel(const GemmArgs g) {
                                    wm, wn);
 }
 
+// ---- 256x256 tile, one 8-wave workgroup per CU: 128 flop per L2 -> LDS byte (the 256x128 ring: 85) -----------------
+// Not persistent on purpose: a persistent variant with the next tile's first stage in flight under the epilogue was
+// 20 % SLOWER (vmcnt also counts the epilogue's stores, and the CUs' store bursts line up); as separate workgroups
+// the tiles drift apart by themselves.
+// A [M,K] K-contiguous, K-step 64 (128-byte rows: whole cache lines per DMA row), two stages of 64 KB.
+// Waves 2 (M) x 4 (N): each 128 x 64 (FI = 8, FJ = 4).  A and (TB = 0) W [N,K]: the 128-row sub-tiles of gemm_kernel's
+// LDS-DMA path (glds_tile / swz), A sub-tile = wm, W sub-tile = wn >> 1.  TB = 1 (input gradients, W [K,N]): four
+// [32 k][128 n] sub-images per stage (k-half, n-half) read by ds_read_b64_tr_b16 exactly as in gemm_r3_kernel.
+template <typename TC, int EPI, bool TB>
+__global__ void __launch_bounds__(512, 2) gemm_big_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef bf16_t T;
+  constexpr int STAGE = 4 * TILE_BYTES;  // A0 | A1 | W0 | W1
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int nblk = g.tiles_m * g.tiles_n;
+  int tile;
+  {  // XCD-aware tile order as in gemm_kernel
+    const int bid = blockIdx.x, xcd = bid & 7, loc = bid >> 3;
+    const int q = nblk >> 3, rm = nblk & 7;
+    tile = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + loc;
+  }
+  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int nk = g.K >> 6;
+  const T* A = static_cast<const T*>(g.A);
+  const T* B = static_cast<const T*>(g.B);
+  const int half = tid >> 8, t256 = tid & 255;
+  // TB = 1: this wave moves piece P = wave (k-rows 4P .. 4P+3, 256 B each) of each of the four sub-images
+  const T* pbt[2] = {nullptr, nullptr};
+  if constexpr (TB) {
+    const int drow = lane >> 4;
+    const int dchunk = (lane & 15) ^ (((drow & 3) << 2) | (wave & 3));
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+      int x = n0 + 128 * nh + 8 * dchunk;
+      if (x > g.N - 8) x = g.N - 8;
+      pbt[nh] = B + (int64_t)(4 * wave + drow) * g.ldb + x;
+    }
+  }
+  auto issue = [&](int s) {
+    char* st = smem + (s & 1) * STAGE;
+    glds_tile<T>(A, g.lda, m0 + 128 * half, s * 64, g.M, st + half * TILE_BYTES, t256);
+    if constexpr (!TB) {
+      glds_tile<T>(B, g.ldb, n0 + 128 * half, s * 64, g.N, st + (2 + half) * TILE_BYTES, t256);
+    } else {
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void*)(pbt[nh] + (int64_t)(64 * s + 32 * kh) * g.ldb),
+              (__attribute__((address_space(3))) void*)(st + 2 * TILE_BYTES + (2 * kh + nh) * R_BSUB + wave * 1024), 16,
+              0, 0);
+    }
+  };
+  const unsigned smem_base = (unsigned)(size_t)((const __attribute__((address_space(3))) char*)smem);
+  const unsigned b_t0 = tr_lane_base(lane, 0, 8 * (wn & 1)), b_t1 = tr_lane_base(lane, 1, 8 * (wn & 1));
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  issue(0);
+  for (int s = 0; s < nk; ++s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stage s landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();                     // ... everybody's; everybody is done reading stage s - 1
+    if (s + 1 < nk) issue(s + 1);
+    const char* la = smem + (s & 1) * STAGE + wm * TILE_BYTES;
+    const char* lb = smem + (s & 1) * STAGE + (2 + (wn >> 1)) * TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      uint4 bf[4], af[8];
+      if constexpr (!TB) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[j] = lds_read128_asm(lb + swz((wn & 1) * 64 + 16 * j + fr, 4 * kk + fq));
+      } else {
+        const unsigned sub = smem_base + (unsigned)((s & 1) * STAGE + 2 * TILE_BYTES + (2 * kk + (wn >> 1)) * R_BSUB);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint2 lo = t_read_tr<0>(sub + (b_t0 ^ (unsigned)(j << 5)));
+          const uint2 hi = t_read_tr<0>(sub + (b_t1 ^ (unsigned)(j << 5)));
+          bf[j] = uint4{lo.x, lo.y, hi.x, hi.y};
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = lds_read128_asm(la + swz(16 * i + fr, 4 * kk + fq));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 4; i < 8; ++i) af[i] = lds_read128_asm(la + swz(16 * i + fr, 4 * kk + fq));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mma_frag<T>(bf[j], af[i], acc[i][j]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 4; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mma_frag<T>(bf[j], af[i], acc[i][j]);
+    }
+  }
+  // (epilogue inputs are fetched here, not before the K loop: the accumulators leave no registers to hold them)
+  EpiPre<T, 8, 4> pre;
+  epi_prefetch<T, 8, 4, EPI>(pre, g, m0 + wm * 128, n0 + wn * 64, fr, fq);
+  // dGELU column sums: two column groups of 128 (wn >> 1), each folded by its 2 x 2 waves; waves 0-3 flush
+  epilogue_tile<T, TC, 8, 4, EPI>(acc, pre, g, m0 + wm * 128, n0 + wn * 64, fr, fq,
+                                  reinterpret_cast<float*>(smem) + (wn >> 1) * 256, wm, wn & 1, wm == 0 ? (tid & 127) : 128);
+}
+
 // ---- weight-gradient kernel: both operands K-major (dW[M,N] += A[K,M]^T . B[K,N]), bf16, split-K + fp32 atomics ----
 // PMC on the register-transposing path (1536x384x65536): MFMA busy 20 %, a third of the LDS cycles are the 2-way
 // conflicts of the transposing ds_write_b64, and with 128x128 tiles the launch pulls 1.2 GB through L2.  Here the
@@ -937,6 +1051,36 @@ int launch_r3(GemmArgs g, hipStream_t st) {
   UWU_LAUNCH_CHECK("gemm_r3");
   return UWU_OK;
 }
+template <typename TC, int EPI, bool TB>
+int launch_big(GemmArgs g, hipStream_t st) {
+  auto kern = gemm_big_kernel<TC, EPI, TB>;
+  constexpr int LDS = 2 * 4 * TILE_BYTES;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_done = true;
+  }
+  g.tiles_m = (g.M + 255) / 256;
+  g.tiles_n = (g.N + 255) / 256;
+  const bool rec = g_prof.on && g_prof.n < GemmProf::MAXP;
+  if (rec) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], st);
+  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(512), LDS, st, g);
+  if (rec) {
+    (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st);
+    g_prof.flops[g_prof.n] = 2.0 * g.M * g.N * g.K;
+    g_prof.kind[g_prof.n] = 0;
+    ++g_prof.n;
+  }
+  UWU_LAUNCH_CHECK("gemm_big");
+  return UWU_OK;
+}
+// 256x256 kernel: taken where the 256x128 ring would be and N is a multiple of 256 (no padded column tiles).
+// Same-box A/B of the whole step: DiT-S/2 +1.8 % (only its two GELU Linears qualify: fc1 + GELU 187 -> 167 us at B = 256),
+// DiT-B/2 +5.5 %, DiT-L/2 +1.9 %, SDXL UNet +-0.  UWU_GEMM_BIG=0 turns it off (A/B comparisons).
+static bool use_big() {
+  const char* e = getenv("UWU_GEMM_BIG");
+  return !(e && e[0] == '0');
+}
 // C[m][n] += sum over the split-K slices of the scratch [split][M][N]; one float4 per thread
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ C,
                                                             int M, int N, int ldc, int split) {
@@ -1076,6 +1220,11 @@ int dispatch_trans(const GemmArgs& g, int ta, int tb, bool acc, int split, hipSt
       const int r3 = pick_r3(g, false);
       if (r3 == 8) {
         if constexpr (hot) {
+          if (g.K % 64 == 0 && g.N % 256 == 0 && use_big()) {
+            if (g.epi == UWU_EPI_BIAS_GELU) return launch_big<TC, UWU_EPI_BIAS_GELU, false>(g, st);
+            if (g.epi == UWU_EPI_NONE) return launch_big<TC, UWU_EPI_NONE, false>(g, st);
+            if (g.epi == UWU_EPI_BIAS) return launch_big<TC, UWU_EPI_BIAS, false>(g, st);
+          }
           if (g.epi == UWU_EPI_NONE) return launch_r3<TC, UWU_EPI_NONE, false, 8>(g, st);
           if (g.epi == UWU_EPI_BIAS) return launch_r3<TC, UWU_EPI_BIAS, false, 8>(g, st);
           if (g.epi == UWU_EPI_BIAS_GELU) return launch_r3<TC, UWU_EPI_BIAS_GELU, false, 8>(g, st);
@@ -1096,6 +1245,10 @@ int dispatch_trans(const GemmArgs& g, int ta, int tb, bool acc, int split, hipSt
   if (ta == 0 && tb == 1) {
     if constexpr (hot) {
       const int r3 = pick_r3(g, true);
+      if (r3 == 8 && g.K % 64 == 0 && g.N % 256 == 0 && use_big()) {
+        if (g.epi == UWU_EPI_DGELU) return launch_big<TC, UWU_EPI_DGELU, true>(g, st);
+        if (g.epi == UWU_EPI_NONE) return launch_big<TC, UWU_EPI_NONE, true>(g, st);
+      }
       if (r3 == 8 && g.epi == UWU_EPI_NONE) return launch_r3<TC, UWU_EPI_NONE, true, 8>(g, st);
       if (r3 == 8 && g.epi == UWU_EPI_DGELU) return launch_r3<TC, UWU_EPI_DGELU, true, 8>(g, st);
       if (r3 == 4 && g.epi == UWU_EPI_NONE) return launch_r3<TC, UWU_EPI_NONE, true, 4>(g, st);
