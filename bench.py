@@ -223,7 +223,7 @@ def main():
             if args.dtype == "bf16" and B == DEFAULT_BATCH and args.model == MODEL and os.path.exists(tj):
                 with open(tj) as f:
                     traffic = round(json.load(f)["hbm_bytes_per_launch"])
-            roof = {"bound": "mfma", "kernel": "bf16 MFMA GEMM family (gemm_kernel / gemm_r3_kernel / gemm_tr_kernel, v_mfma_f32_16x16x32_bf16; fwd+dgrad+wgrad launches)",
+            roof = {"bound": "mfma", "kernel": "bf16 MFMA GEMM family (gemm_kernel / gemm_r3_kernel / gemm_big_kernel / gemm_tr_kernel, v_mfma_f32_16x16x32_bf16; fwd+dgrad+wgrad launches)",
                     "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": traffic, "launches_per_step": n.value // n_prof,
                     "avg_launch_us": round(ms.value * 1e3 / n.value, 2),

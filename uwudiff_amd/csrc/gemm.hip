@@ -1075,7 +1075,8 @@ int launch_big(GemmArgs g, hipStream_t st) {
   return UWU_OK;
 }
 // 256x256 kernel: taken where the 256x128 ring would be and N is a multiple of 256 (no padded column tiles).
-// Same-box A/B of the whole step: DiT-S/2 +1.8 % (only its two GELU Linears qualify: fc1 + GELU 187 -> 167 us at B = 256),
+// Same-box A/B of the whole step: DiT-S/2 +1.8 % (only its two GELU Linears qualify: fc1 + GELU 187 -> 167 us at B = 256;
+// the dGELU input gradient is a wash there),
 // DiT-B/2 +5.5 %, DiT-L/2 +1.9 %, SDXL UNet +-0.  UWU_GEMM_BIG=0 turns it off (A/B comparisons).
 static bool use_big() {
   const char* e = getenv("UWU_GEMM_BIG");
