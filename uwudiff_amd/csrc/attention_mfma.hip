@@ -483,22 +483,31 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
     }
     if constexpr (DQ) __syncthreads();  // dS image complete for all keys
     // ---- phase 2: dQ^T[d][q] = K^T[d][key] . dS^T[key][q]; wave w owns q-block (w&3) and d-blocks 2(w>>2), +1
+    // Both d-blocks advance together (two independent MFMA chains sharing the dS fragment), two key steps per
+    // iteration with all six fragment reads issued first; the swizzled address of key step kk is base ^ (kk << 6)
+    // (chunk = 4 kk + fq only flips address bits 6-8), so the loop carries no address arithmetic.  The first version
+    // ran one dependent read -> MFMA chain per d-block with the full swizzle per step.
     if constexpr (DQ) {
-      const int qblk = wave & 3;
+      const int qblk = wave & 3, db0 = 2 * (wave >> 2);
       bf16_t* dqrow = a.dq + (int64_t)b * a.T * a.ldq + hd * 64 + (int64_t)(t * 64 + 16 * qblk + fr) * a.ldq;
-#pragma unroll
-      for (int dbi = 0; dbi < 2; ++dbi) {
-        const int db = 2 * (wave >> 2) + dbi;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int kk = 0; kk < nk32; ++kk) {
-          uint4 ka = *reinterpret_cast<const uint4*>(ktimg + off512(16 * db + fr, 4 * kk + fq));
-          uint4 da = *reinterpret_cast<const uint4*>(dsimg + off512(16 * qblk + fr, 4 * kk + fq));
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&ka),
-                                                        *reinterpret_cast<const bf16x8*>(&da), acc, 0, 0, 0);
-        }
-        // D[row = d = 16db + 4fq + reg][col = q = fr]: 4 consecutive d of one query row per lane
-        store4(dqrow + 16 * db + 4 * fq, acc * a.scale);
+      const int k0o = off512(16 * db0 + fr, fq), k1o = off512(16 * db0 + 16 + fr, fq), dso = off512(16 * qblk + fr, fq);
+      auto frag = [](const char* img, int off, int kk) { return *reinterpret_cast<const uint4*>(img + (off ^ (kk << 6))); };
+      auto mma16 = [](const uint4& x, const uint4& y, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&x),
+                                                       *reinterpret_cast<const bf16x8*>(&y), c, 0, 0, 0);
+      };
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      for (int kk = 0; kk < nk32; kk += 2) {  // T is a multiple of 64: nk32 is even
+        const uint4 ka0 = frag(ktimg, k0o, kk), kb0 = frag(ktimg, k1o, kk), d0 = frag(dsimg, dso, kk);
+        const uint4 ka1 = frag(ktimg, k0o, kk + 1), kb1 = frag(ktimg, k1o, kk + 1), d1 = frag(dsimg, dso, kk + 1);
+        acc0 = mma16(ka0, d0, acc0);
+        acc1 = mma16(kb0, d0, acc1);
+        acc0 = mma16(ka1, d1, acc0);
+        acc1 = mma16(kb1, d1, acc1);
       }
+      // D[row = d = 16db + 4fq + reg][col = q = fr]: 4 consecutive d of one query row per lane
+      store4(dqrow + 16 * db0 + 4 * fq, acc0 * a.scale);
+      store4(dqrow + 16 * db0 + 16 + 4 * fq, acc1 * a.scale);
     }
     if (t + 1 < nt) store_tile((t + 1) & 1);
     __syncthreads();  // dS image free again; next stage visible
