@@ -1078,9 +1078,11 @@ int launch_big(GemmArgs g, hipStream_t st) {
 // Same-box A/B of the whole step: DiT-S/2 +1.8 % (only its two GELU Linears qualify: fc1 + GELU 187 -> 167 us at B = 256;
 // the dGELU input gradient is a wash there),
 // DiT-B/2 +5.5 %, DiT-L/2 +1.9 %, SDXL UNet +-0.  UWU_GEMM_BIG=0 turns it off (A/B comparisons).
-static bool use_big() {
+// (A masked ragged last column tile was tried on DiT-XL/2's N = 3456 / 1152 Linears: +0.4 % at 4 % padding, -1.8 % at
+// 11 % -- not taken.)
+static bool use_big(const GemmArgs& g) {
   const char* e = getenv("UWU_GEMM_BIG");
-  return !(e && e[0] == '0');
+  return !(e && e[0] == '0') && g.K % 64 == 0 && g.N % 256 == 0;
 }
 // C[m][n] += sum over the split-K slices of the scratch [split][M][N]; one float4 per thread
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ C,
@@ -1221,7 +1223,7 @@ int dispatch_trans(const GemmArgs& g, int ta, int tb, bool acc, int split, hipSt
       const int r3 = pick_r3(g, false);
       if (r3 == 8) {
         if constexpr (hot) {
-          if (g.K % 64 == 0 && g.N % 256 == 0 && use_big()) {
+          if (use_big(g)) {
             if (g.epi == UWU_EPI_BIAS_GELU) return launch_big<TC, UWU_EPI_BIAS_GELU, false>(g, st);
             if (g.epi == UWU_EPI_NONE) return launch_big<TC, UWU_EPI_NONE, false>(g, st);
             if (g.epi == UWU_EPI_BIAS) return launch_big<TC, UWU_EPI_BIAS, false>(g, st);
@@ -1246,7 +1248,7 @@ int dispatch_trans(const GemmArgs& g, int ta, int tb, bool acc, int split, hipSt
   if (ta == 0 && tb == 1) {
     if constexpr (hot) {
       const int r3 = pick_r3(g, true);
-      if (r3 == 8 && g.K % 64 == 0 && g.N % 256 == 0 && use_big()) {
+      if (r3 == 8 && use_big(g)) {
         if (g.epi == UWU_EPI_DGELU) return launch_big<TC, UWU_EPI_DGELU, true>(g, st);
         if (g.epi == UWU_EPI_NONE) return launch_big<TC, UWU_EPI_NONE, true>(g, st);
       }
