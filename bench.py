@@ -23,8 +23,9 @@ import torch.distributed as dist  # noqa: E402
 
 MODEL = "DiT-S/2"
 # per-GPU batch: the config does not fix it (the reference yaml trains at 16); sweep on one MI355X:
-# 16 -> 3.3k, 64 -> 8.4k, 128 -> 11.1k, 256 -> 12.5k, 512 -> 13.2k, 768 -> 13.4k images/s.  512 = 22 GB of activations.
-DEFAULT_BATCH = 512
+# 16 -> 3.4k, 64 -> 8.9k, 128 -> 11.7k, 256 -> 13.2k, 512 -> 14.0k, 768 -> 14.5k images/s.  768 = 33 GB of activations, and
+# M = 196608 token rows is a whole number of rounds of the one-workgroup-per-CU GEMM tiles (1024 x 192 rows, 768 x 256).
+DEFAULT_BATCH = 768
 # step GFLOP per image (3 x forward, no recompute)
 STEP_GFLOP = {"DiT-S/2": 36.3, "DiT-B/2": 138.0, "DiT-L/2": 484.0, "DiT-XL/2": 711.7,
               "SDXL-UNet": {32: 1283.0, 128: 20284.0}}  # the UNet2DConditionModel shape the reference YAMLs build
@@ -223,7 +224,7 @@ def main():
             if args.dtype == "bf16" and B == DEFAULT_BATCH and args.model == MODEL and os.path.exists(tj):
                 with open(tj) as f:
                     traffic = round(json.load(f)["hbm_bytes_per_launch"])
-            roof = {"bound": "mfma", "kernel": "bf16 MFMA GEMM family (gemm_kernel / gemm_r3_kernel / gemm_big_kernel / gemm_tr_kernel, v_mfma_f32_16x16x32_bf16; fwd+dgrad+wgrad launches)",
+            roof = {"bound": "mfma", "kernel": "bf16 MFMA GEMM family (gemm_kernel / gemm_r3_kernel / gemm_big_kernel / gemm_wide_kernel / gemm_tr_kernel, v_mfma_f32_16x16x32_bf16; fwd+dgrad+wgrad launches)",
                     "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": traffic, "launches_per_step": n.value // n_prof,
                     "avg_launch_us": round(ms.value * 1e3 / n.value, 2),

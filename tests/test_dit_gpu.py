@@ -95,14 +95,14 @@ def test_dit_bf16_full_size_batch_matches_oracle():
 
 
 def test_dit_bench_batch_gradients_are_additive_over_samples():
-    """Size-independent property at the bench's launch shapes (per-GPU batch 512, M = 131072 tokens): the gradient of a
+    """Size-independent property at the bench's launch shapes (per-GPU batch 768, M = 196608 tokens): the gradient of a
     sum over samples equals the sum of the gradients of two half batches accumulated into the flat buffer (the two
     runs take different tile counts, K-slice counts and workspace sizes)."""
     from uwudiff_amd.dit import DiT
 
     torch.manual_seed(11)
     model = DiT.from_config("DiT-S/2", cond_dim=1280, init="random", compute_dtype="bf16").cuda()
-    B = 512
+    B = 768
     x, t = torch.randn(B, 4, 32, 32, device="cuda"), torch.randint(0, 1000, (B,), device="cuda").float()
     c, w = torch.randn(B, 1280, device="cuda"), torch.randn(B, 4, 32, 32, device="cuda") / 4096
 

@@ -211,6 +211,31 @@ def test_gemm_big_tile_matches_128_kernel(monkeypatch):
         assert torch.equal(ref, got)
 
 
+def test_gemm_wide_tile_matches_128_kernel(monkeypatch):
+    """192x384 kernel (gemm_wide_kernel) on the N = 384 / 1152 Linears: same bits as the 128x128 kernel."""
+    from uwudiff_amd import lib as L
+    from uwudiff_amd import ops
+
+    def both(fn):
+        monkeypatch.setenv("UWU_GEMM_R3", "0")
+        monkeypatch.setenv("UWU_GEMM_WIDE", "0")
+        ref = fn()
+        monkeypatch.setenv("UWU_GEMM_R3", "1")
+        monkeypatch.setenv("UWU_GEMM_WIDE", "1")
+        return ref, fn()
+
+    for M, N, K in [(65536, 384, 1536), (65536, 1152, 384), (50000, 384, 384)]:
+        a, b = _operands(M, N, K, False, False, torch.bfloat16, ints=False, seed=41)
+        bias = torch.randn(N, generator=torch.Generator().manual_seed(42)).cuda()
+        for kw in ({}, dict(bias=bias, epilogue=L.EPI_BIAS)):
+            ref, got = both(lambda: ops.gemm(a, b, **kw))
+            assert torch.equal(ref, got)
+    for M, N, K in [(65536, 384, 1152), (50000, 384, 1536), (65536, 1152, 384)]:  # input gradients: dy [M,K] x W [K,N]
+        dy, w = _operands(M, N, K, False, True, torch.bfloat16, ints=False, seed=43)
+        ref, got = both(lambda: ops.gemm(dy, w, trans_b=True))
+        assert torch.equal(ref, got)
+
+
 # ---- K-major x K-major accumulate kernel (gemm_tr_kernel: LDS-DMA + ds_read_b64_tr_b16), used for the weight
 # gradients dW += dY^T X with split-K.  Integer operands make every partial sum exact, so the fp32 atomics are
 # order-independent and the result must equal both the exact matmul and the 128x128 kernel (UWU_GEMM_TR=0).

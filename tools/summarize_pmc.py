@@ -32,7 +32,7 @@ fetch, nf, pf = load(sys.argv[1], "FETCH_SIZE")
 write, nw, pw = load(sys.argv[2], "WRITE_SIZE")
 out = {
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline",
-    "kernel_family": "bf16 MFMA GEMM family: gemm_kernel / gemm_r3_kernel / gemm_big_kernel / gemm_tr_kernel (+ splitk_reduce bytes), fwd + dgrad + wgrad launches",
+    "kernel_family": "bf16 MFMA GEMM family: gemm_kernel / gemm_r3_kernel / gemm_big_kernel / gemm_wide_kernel / gemm_tr_kernel (+ splitk_reduce bytes), fwd + dgrad + wgrad launches",
     "launches": nf,
     "fetch_kib_sum_raw": fetch, "write_kib_sum": write,
     "hbm_bytes_per_launch": (2.0 * fetch / nf + write / nw) * 1024.0,

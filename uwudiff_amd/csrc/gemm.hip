@@ -795,6 +795,142 @@ __global__ void __launch_bounds__(512, 2) gemm_big_kernel(const GemmArgs g) {
                                   reinterpret_cast<float*>(smem) + (wn >> 1) * 256, wm, wn & 1, wm == 0 ? (tid & 127) : 128);
 }
 
+// ---- 192x384 tile, 8 waves (2 x 4 of 96 x 96: FI = FJ = 6): the N = 384 / 1152 Linears ---------------------------
+// With N = 384 the 256x128 ring reads every A row-panel three times (once per column tile); this tile covers the whole
+// width, so A crosses L2 -> LDS once (128 flop per byte, as the 256x256 kernel, without its column padding).
+// Same structure as gemm_big_kernel: K-step 64 (128-byte rows), two stages of 72 KB, one workgroup per CU.
+// Images: A 192 rows | W 384 rows (TB = 0, swz) or 2 x 3 sub-images [32 k][128 n] (TB = 1, transposing reads).
+template <typename TC, int EPI, bool TB>
+__global__ void __launch_bounds__(512, 2) gemm_wide_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef bf16_t T;
+  constexpr int FI = 6, FJ = 6, BMR = 192, BNC = 384;
+  constexpr int A_BYTES = BMR * ROW_BYTES, STAGE = (BMR + BNC) * ROW_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int nblk = g.tiles_m * g.tiles_n;
+  int tile;
+  {  // XCD-aware tile order as in gemm_kernel
+    const int bid = blockIdx.x, xcd = bid & 7, loc = bid >> 3;
+    const int q = nblk >> 3, rm = nblk & 7;
+    tile = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + loc;
+  }
+  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  const int m0 = tm * BMR, n0 = tn * BNC;
+  const int nk = g.K >> 6;
+  const T* A = static_cast<const T*>(g.A);
+  const T* B = static_cast<const T*>(g.B);
+
+  // per-lane DMA sources; piece p = wave + 8 q is rows 8p .. 8p+7 of an image (lane: row lane>>3, 16-byte slot lane&7
+  // receives the logical chunk the swizzle assigns to that slot).  Rows past the operand are clamped.
+  const T* pa[3];
+  const T* pb[6];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int row = 8 * (wave + 8 * q) + (lane >> 3);
+    const int c = ((lane & 7) ^ (row >> 1) ^ (row >> 4)) & 7;
+    int grow = m0 + row;
+    if (grow >= g.M) grow = g.M - 1;
+    pa[q] = A + (int64_t)grow * g.lda + 8 * c;
+  }
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    if constexpr (!TB) {
+      const int row = 8 * (wave + 8 * q) + (lane >> 3);
+      const int c = ((lane & 7) ^ (row >> 1) ^ (row >> 4)) & 7;
+      int grow = n0 + row;
+      if (grow >= g.N) grow = g.N - 1;
+      pb[q] = B + (int64_t)grow * g.ldb + 8 * c;
+    } else {  // q = 3 kh + nh: piece P = wave (k-rows 4P .. 4P+3) of sub-image (kh, nh)
+      const int kh = q / 3, nh = q - 3 * kh;
+      const int drow = lane >> 4;
+      const int dchunk = (lane & 15) ^ (((drow & 3) << 2) | (wave & 3));
+      int x = n0 + 128 * nh + 8 * dchunk;
+      if (x > g.N - 8) x = g.N - 8;
+      pb[q] = B + (int64_t)(32 * kh + 4 * wave + drow) * g.ldb + x;
+    }
+  }
+  auto issue = [&](int s) {
+    char* st = smem + (s & 1) * STAGE;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[q] + 64 * s),
+                                       (__attribute__((address_space(3))) void*)(st + (wave + 8 * q) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      if constexpr (!TB)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb[q] + 64 * s),
+                                         (__attribute__((address_space(3))) void*)(st + A_BYTES + (wave + 8 * q) * 1024),
+                                         16, 0, 0);
+      else
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb[q] + (int64_t)(64 * s) * g.ldb),
+                                         (__attribute__((address_space(3))) void*)(st + A_BYTES + q * R_BSUB + wave * 1024),
+                                         16, 0, 0);
+    }
+  };
+  const unsigned smem_base = (unsigned)(size_t)((const __attribute__((address_space(3))) char*)smem);
+  // TB = 1: fragment j starts at column 96 wn + 16 j: sub-image (col >> 7), first 8-column chunk (col & 127) >> 3
+  unsigned tb0[FJ], tb1[FJ];
+  if constexpr (TB) {
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) {
+      const int col = 96 * wn + 16 * j;
+      tb0[j] = A_BYTES + (col >> 7) * R_BSUB + tr_lane_base(lane, 0, (col & 127) >> 3);
+      tb1[j] = A_BYTES + (col >> 7) * R_BSUB + tr_lane_base(lane, 1, (col & 127) >> 3);
+    }
+  }
+  f32x4 acc[FI][FJ];
+#pragma unroll
+  for (int i = 0; i < FI; ++i)
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  issue(0);
+  for (int s = 0; s < nk; ++s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stage s landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();                     // ... everybody's; everybody is done reading stage s - 1
+    if (s + 1 < nk) issue(s + 1);
+    const char* la = smem + (s & 1) * STAGE;
+    const char* lb = la + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      uint4 bf[FJ], af[FI];
+      if constexpr (!TB) {
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) bf[j] = lds_read128_asm(lb + swz(96 * wn + 16 * j + fr, 4 * kk + fq));
+      } else {
+        const unsigned sb = smem_base + (unsigned)((s & 1) * STAGE + kk * 3 * R_BSUB);
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) {
+          const uint2 lo = t_read_tr<0>(sb + tb0[j]);
+          const uint2 hi = t_read_tr<0>(sb + tb1[j]);
+          bf[j] = uint4{lo.x, lo.y, hi.x, hi.y};
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) af[i] = lds_read128_asm(la + swz(96 * wm + 16 * i + fr, 4 * kk + fq));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 3; i < FI; ++i) af[i] = lds_read128_asm(la + swz(96 * wm + 16 * i + fr, 4 * kk + fq));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) mma_frag<T>(bf[j], af[i], acc[i][j]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 3; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) mma_frag<T>(bf[j], af[i], acc[i][j]);
+    }
+  }
+  EpiPre<T, FI, FJ> pre;
+  epi_prefetch<T, FI, FJ, EPI>(pre, g, m0 + wm * 96, n0 + wn * 96, fr, fq);
+  epilogue_tile<T, TC, FI, FJ, EPI>(acc, pre, g, m0 + wm * 96, n0 + wn * 96, fr, fq, nullptr, wm, wn & 1);
+}
+
 // ---- weight-gradient kernel: both operands K-major (dW[M,N] += A[K,M]^T . B[K,N]), bf16, split-K + fp32 atomics ----
 // PMC on the register-transposing path (1536x384x65536): MFMA busy 20 %, a third of the LDS cycles are the 2-way
 // conflicts of the transposing ds_write_b64, and with 128x128 tiles the launch pulls 1.2 GB through L2.  Here the
@@ -1074,6 +1210,42 @@ int launch_big(GemmArgs g, hipStream_t st) {
   UWU_LAUNCH_CHECK("gemm_big");
   return UWU_OK;
 }
+template <typename TC, int EPI, bool TB>
+int launch_wide(GemmArgs g, hipStream_t st) {
+  auto kern = gemm_wide_kernel<TC, EPI, TB>;
+  constexpr int LDS = 2 * (192 + 384) * ROW_BYTES;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_done = true;
+  }
+  g.tiles_m = (g.M + 191) / 192;
+  g.tiles_n = g.N / 384;
+  const bool rec = g_prof.on && g_prof.n < GemmProf::MAXP;
+  if (rec) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], st);
+  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(512), LDS, st, g);
+  if (rec) {
+    (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st);
+    g_prof.flops[g_prof.n] = 2.0 * g.M * g.N * g.K;
+    g_prof.kind[g_prof.n] = 0;
+    ++g_prof.n;
+  }
+  UWU_LAUNCH_CHECK("gemm_wide");
+  return UWU_OK;
+}
+// 192x384 kernel: N a multiple of 384 (and not of 256), and enough tiles that the last round of one-workgroup-per-CU
+// tiles is not mostly empty.  Same box, M = 131072: qkv fwd 193 -> 183 us, fc2 fwd 207 -> 185, qkv / fc1 input gradients
+// 149 -> 138 / 191 -> 172; at M = 65536 (342 tiles of 192 rows = 1.3 rounds of 256 CUs) it loses 5-10 %, hence the
+// fill rule.  UWU_GEMM_WIDE=0 turns it off, =1 forces it (tests, A/B comparisons).
+static bool use_wide(const GemmArgs& g) {
+  if (g.K % 64 || g.N % 384 || g.N % 256 == 0) return false;
+  const char* e = getenv("UWU_GEMM_WIDE");
+  if (e && e[0] == '0') return false;
+  if (e && e[0] == '1') return true;
+  const int64_t tiles = (int64_t)((g.M + 191) / 192) * (g.N / 384);
+  const int64_t rounds = (tiles + 255) / 256;
+  return tiles * 100 >= rounds * 256 * 85;
+}
 // 256x256 kernel: taken where the 256x128 ring would be and N is a multiple of 256 (no padded column tiles).
 // Same-box A/B of the whole step: DiT-S/2 +1.8 % (only its two GELU Linears qualify: fc1 + GELU 187 -> 167 us at B = 256;
 // the dGELU input gradient is a wash there),
@@ -1223,6 +1395,10 @@ int dispatch_trans(const GemmArgs& g, int ta, int tb, bool acc, int split, hipSt
       const int r3 = pick_r3(g, false);
       if (r3 == 8) {
         if constexpr (hot) {
+          if (use_wide(g)) {
+            if (g.epi == UWU_EPI_NONE) return launch_wide<TC, UWU_EPI_NONE, false>(g, st);
+            if (g.epi == UWU_EPI_BIAS) return launch_wide<TC, UWU_EPI_BIAS, false>(g, st);
+          }
           if (use_big(g)) {
             if (g.epi == UWU_EPI_BIAS_GELU) return launch_big<TC, UWU_EPI_BIAS_GELU, false>(g, st);
             if (g.epi == UWU_EPI_NONE) return launch_big<TC, UWU_EPI_NONE, false>(g, st);
@@ -1248,6 +1424,7 @@ int dispatch_trans(const GemmArgs& g, int ta, int tb, bool acc, int split, hipSt
   if (ta == 0 && tb == 1) {
     if constexpr (hot) {
       const int r3 = pick_r3(g, true);
+      if (r3 == 8 && use_wide(g) && g.epi == UWU_EPI_NONE) return launch_wide<TC, UWU_EPI_NONE, true>(g, st);
       if (r3 == 8 && use_big(g)) {
         if (g.epi == UWU_EPI_DGELU) return launch_big<TC, UWU_EPI_DGELU, true>(g, st);
         if (g.epi == UWU_EPI_NONE) return launch_big<TC, UWU_EPI_NONE, true>(g, st);
