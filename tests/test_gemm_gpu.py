@@ -236,6 +236,40 @@ def test_gemm_wide_tile_matches_128_kernel(monkeypatch):
         assert torch.equal(ref, got)
 
 
+def test_gemm_m64_tile_matches_128_kernel(monkeypatch):
+    """64x128 kernel (gemm_m64_kernel, small token counts): same bits as the 128x128 kernel."""
+    from uwudiff_amd import lib as L
+    from uwudiff_amd import ops
+
+    def both(fn):
+        monkeypatch.setenv("UWU_GEMM_M64", "0")
+        ref = fn()
+        monkeypatch.setenv("UWU_GEMM_M64", "1")
+        return ref, fn()
+
+    for M, N, K in [(4096, 384, 384), (4096, 1152, 384), (4000, 1536, 384), (1000, 200, 128)]:
+        a, b = _operands(M, N, K, False, False, torch.bfloat16, ints=False, seed=51)
+        bias = torch.randn(N, generator=torch.Generator().manual_seed(52)).cuda()
+        for kw in ({}, dict(bias=bias, epilogue=L.EPI_BIAS)):
+            ref, got = both(lambda: ops.gemm(a, b, **kw))
+            assert torch.equal(ref, got)
+        (u0, f0), (u1, f1) = both(lambda: ops.gemm(a, b, bias=bias, epilogue=L.EPI_BIAS_GELU))
+        assert torch.equal(u0, u1) and torch.equal(f0, f1)
+        dy, w = _operands(M, N, K, False, True, torch.bfloat16, ints=False, seed=53)  # input gradient: dy [M,K] x W [K,N]
+        ref, got = both(lambda: ops.gemm(dy, w, trans_b=True))
+        assert torch.equal(ref, got)
+        u = (torch.randn(M, N, generator=torch.Generator().manual_seed(54)) * 1.5).bfloat16().cuda()
+
+        def run():
+            cs = torch.zeros(N, device="cuda")
+            out = ops.gemm(dy, w, trans_b=True, aux=u, epilogue=L.EPI_DGELU, out2=cs)
+            return (out[0] if isinstance(out, tuple) else out), cs
+
+        (d0, s0), (d1, s1) = both(run)
+        assert torch.equal(d0, d1)
+        torch.testing.assert_close(s0, s1, rtol=1e-3, atol=0.2)  # fp32 atomics: order differs
+
+
 # ---- K-major x K-major accumulate kernel (gemm_tr_kernel: LDS-DMA + ds_read_b64_tr_b16), used for the weight
 # gradients dW += dY^T X with split-K.  Integer operands make every partial sum exact, so the fp32 atomics are
 # order-independent and the result must equal both the exact matmul and the 128x128 kernel (UWU_GEMM_TR=0).

@@ -931,6 +931,113 @@ __global__ void __launch_bounds__(512, 2) gemm_wide_kernel(const GemmArgs g) {
   epilogue_tile<T, TC, FI, FJ, EPI>(acc, pre, g, m0 + wm * 96, n0 + wn * 96, fr, fq, nullptr, wm, wn & 1);
 }
 
+// ---- 64x128 tile for small token counts (a 128x128 grid that would leave most CUs idle) ---------------------------
+// Per-GPU batch 16 (the reference yaml) is M = 4096 rows: 32 x 3 = 96 tiles of 128x128 for an N = 384 Linear on 256
+// CUs.  Half-height tiles double the workgroups; 4 waves of 32 x 64 (FI = 2, FJ = 4), K-step 64, two LDS-DMA stages of
+// 24 KB.  Operand images as in gemm_kernel's LDS-DMA path (TB = 0) / gemm_r3_kernel's transposing reads (TB = 1).
+template <typename TC, int EPI, bool TB>
+__global__ void __launch_bounds__(256, 2) gemm_m64_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef bf16_t T;
+  constexpr int A_BYTES = 64 * ROW_BYTES, STAGE = A_BYTES + TILE_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int nblk = g.tiles_m * g.tiles_n;
+  int tile;
+  {  // XCD-aware tile order as in gemm_kernel
+    const int bid = blockIdx.x, xcd = bid & 7, loc = bid >> 3;
+    const int q = nblk >> 3, rm = nblk & 7;
+    tile = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + loc;
+  }
+  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  const int m0 = tm * 64, n0 = tn * 128;
+  const int nk = g.K >> 6;
+  const T* A = static_cast<const T*>(g.A);
+  const T* B = static_cast<const T*>(g.B);
+  // A: pieces p = wave + 4 q (rows 8p .. 8p+7); TB = 1: piece P = wave + 4 q of the k-half sub-images
+  const T* pa[2];
+  const T* pbt[2] = {nullptr, nullptr};
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int row = 8 * (wave + 4 * q) + (lane >> 3);
+    const int c = ((lane & 7) ^ (row >> 1) ^ (row >> 4)) & 7;
+    int grow = m0 + row;
+    if (grow >= g.M) grow = g.M - 1;
+    pa[q] = A + (int64_t)grow * g.lda + 8 * c;
+    if constexpr (TB) {
+      const int drow = lane >> 4;
+      const int dchunk = (lane & 15) ^ (((drow & 3) << 2) | (wave & 3));
+      int x = n0 + 8 * dchunk;
+      if (x > g.N - 8) x = g.N - 8;
+      pbt[q] = B + (int64_t)(4 * (wave + 4 * q) + drow) * g.ldb + x;
+    }
+  }
+  auto issue = [&](int s) {
+    char* st = smem + (s & 1) * STAGE;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[q] + 64 * s),
+                                       (__attribute__((address_space(3))) void*)(st + (wave + 4 * q) * 1024), 16, 0, 0);
+    if constexpr (!TB) {
+      glds_tile<T>(B, g.ldb, n0, s * 64, g.N, st + A_BYTES, tid);
+    } else {
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void*)(pbt[q] + (int64_t)(64 * s + 32 * kh) * g.ldb),
+              (__attribute__((address_space(3))) void*)(st + A_BYTES + kh * R_BSUB + (wave + 4 * q) * 1024), 16, 0, 0);
+    }
+  };
+  const unsigned smem_base = (unsigned)(size_t)((const __attribute__((address_space(3))) char*)smem);
+  const unsigned b_t0 = A_BYTES + tr_lane_base(lane, 0, 8 * wn), b_t1 = A_BYTES + tr_lane_base(lane, 1, 8 * wn);
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  EpiPre<T, 2, 4> pre;
+  epi_prefetch<T, 2, 4, EPI>(pre, g, m0 + wm * 32, n0 + wn * 64, fr, fq);
+
+  issue(0);
+  for (int s = 0; s < nk; ++s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stage s landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();                     // ... everybody's; everybody is done reading stage s - 1
+    if (s + 1 < nk) issue(s + 1);
+    const char* la = smem + (s & 1) * STAGE;
+    const char* lb = la + A_BYTES;
+    uint4 af[2][2], bf[2][4];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[kk][i] = lds_read128_asm(la + swz(wm * 32 + 16 * i + fr, 4 * kk + fq));
+      if constexpr (!TB) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[kk][j] = lds_read128_asm(lb + swz(wn * 64 + 16 * j + fr, 4 * kk + fq));
+      } else {
+        const unsigned sb = smem_base + (unsigned)((s & 1) * STAGE + kk * R_BSUB);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint2 lo = t_read_tr<0>(sb + (b_t0 ^ (unsigned)(j << 5)));
+          const uint2 hi = t_read_tr<0>(sb + (b_t1 ^ (unsigned)(j << 5)));
+          bf[kk][j] = uint4{lo.x, lo.y, hi.x, hi.y};
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mma_frag<T>(bf[kk][j], af[kk][i], acc[i][j]);
+  }
+  epilogue_tile<T, TC, 2, 4, EPI>(acc, pre, g, m0 + wm * 32, n0 + wn * 64, fr, fq, reinterpret_cast<float*>(smem), wm, wn);
+}
+
 // ---- weight-gradient kernel: both operands K-major (dW[M,N] += A[K,M]^T . B[K,N]), bf16, split-K + fp32 atomics ----
 // PMC on the register-transposing path (1536x384x65536): MFMA busy 20 %, a third of the LDS cycles are the 2-way
 // conflicts of the transposing ds_write_b64, and with 128x128 tiles the launch pulls 1.2 GB through L2.  Here the
@@ -1211,6 +1318,33 @@ int launch_big(GemmArgs g, hipStream_t st) {
   return UWU_OK;
 }
 template <typename TC, int EPI, bool TB>
+int launch_m64(GemmArgs g, hipStream_t st) {
+  auto kern = gemm_m64_kernel<TC, EPI, TB>;
+  constexpr int LDS = 2 * (64 * ROW_BYTES + TILE_BYTES);
+  g.tiles_m = (g.M + 63) / 64;
+  g.tiles_n = (g.N + 127) / 128;
+  const bool rec = g_prof.on && g_prof.n < GemmProf::MAXP;
+  if (rec) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], st);
+  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(256), LDS, st, g);
+  if (rec) {
+    (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st);
+    g_prof.flops[g_prof.n] = 2.0 * g.M * g.N * g.K;
+    g_prof.kind[g_prof.n] = 0;
+    ++g_prof.n;
+  }
+  UWU_LAUNCH_CHECK("gemm_m64");
+  return UWU_OK;
+}
+// 64x128 kernel: when the 128x128 grid has fewer tiles than the chip has CUs.  UWU_GEMM_M64=0 turns it off.
+static bool use_m64(const GemmArgs& g, bool tb) {
+  const char* e = getenv("UWU_GEMM_M64");
+  if (e && e[0] == '0') return false;
+  if (g.K % 64 || (((uintptr_t)g.A | (uintptr_t)g.B) & 15) || g.lda % 8 || g.ldb % 8) return false;
+  if (tb && (g.N % 8 || g.N < 8)) return false;
+  const int64_t tiles = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128);
+  return tiles < 256 && g.M > 64;
+}
+template <typename TC, int EPI, bool TB>
 int launch_wide(GemmArgs g, hipStream_t st) {
   auto kern = gemm_wide_kernel<TC, EPI, TB>;
   constexpr int LDS = 2 * (192 + 384) * ROW_BYTES;
@@ -1411,6 +1545,13 @@ int dispatch_trans(const GemmArgs& g, int ta, int tb, bool acc, int split, hipSt
         return launch_r3<TC, -1, false, 8>(g, st);
       }
     }
+    if constexpr (hot) {
+      if (use_m64(g, false)) {
+        if (g.epi == UWU_EPI_NONE) return launch_m64<TC, UWU_EPI_NONE, false>(g, st);
+        if (g.epi == UWU_EPI_BIAS) return launch_m64<TC, UWU_EPI_BIAS, false>(g, st);
+        if (g.epi == UWU_EPI_BIAS_GELU) return launch_m64<TC, UWU_EPI_BIAS_GELU, false>(g, st);
+      }
+    }
     if (g.K % GT<T>::BK == 0 && !no_glds()) {
       if constexpr (hot) {
         if (g.epi == UWU_EPI_NONE) return launch<T, TC, false, false, false, true, UWU_EPI_NONE>(g, split, st);
@@ -1431,6 +1572,10 @@ int dispatch_trans(const GemmArgs& g, int ta, int tb, bool acc, int split, hipSt
       }
       if (r3 == 8 && g.epi == UWU_EPI_NONE) return launch_r3<TC, UWU_EPI_NONE, true, 8>(g, st);
       if (r3 == 8 && g.epi == UWU_EPI_DGELU) return launch_r3<TC, UWU_EPI_DGELU, true, 8>(g, st);
+      if (r3 != 8 && use_m64(g, true)) {
+        if (g.epi == UWU_EPI_NONE) return launch_m64<TC, UWU_EPI_NONE, true>(g, st);
+        if (g.epi == UWU_EPI_DGELU) return launch_m64<TC, UWU_EPI_DGELU, true>(g, st);
+      }
       if (r3 == 4 && g.epi == UWU_EPI_NONE) return launch_r3<TC, UWU_EPI_NONE, true, 4>(g, st);
       if (r3 == 4 && g.epi == UWU_EPI_DGELU) return launch_r3<TC, UWU_EPI_DGELU, true, 4>(g, st);
       if (g.epi == UWU_EPI_NONE) return launch<T, TC, false, true, false, false, UWU_EPI_NONE>(g, split, st);
