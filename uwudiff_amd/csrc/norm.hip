@@ -5,6 +5,25 @@
 #include "common.h"
 
 namespace {
+// streaming (nontemporal) 16-byte accesses for tensors a kernel touches once
+__device__ __forceinline__ f32x8 load8_nt(const float* p) { return load8(p); }
+__device__ __forceinline__ f32x8 load8_nt(const bf16_t* p) {
+  typedef unsigned nu32x4 __attribute__((ext_vector_type(4)));
+  nu32x4 raw = __builtin_nontemporal_load(reinterpret_cast<const nu32x4*>(p));
+  bf16x8 v = *reinterpret_cast<bf16x8*>(&raw);
+  f32x8 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r[i] = (float)v[i];
+  return r;
+}
+__device__ __forceinline__ void store8_nt(float* p, f32x8 v) { store8(p, v); }
+__device__ __forceinline__ void store8_nt(bf16_t* p, f32x8 v) {
+  typedef unsigned nu32x4 __attribute__((ext_vector_type(4)));
+  bf16x8 o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (bf16_t)v[i];
+  __builtin_nontemporal_store(*reinterpret_cast<nu32x4*>(&o), reinterpret_cast<nu32x4*>(p));
+}
 
 constexpr int MAX_D = 4096;  // 16-byte vectors: 8 elements per lane, NIT = ceil(D/512) (template parameter)
 
@@ -27,16 +46,19 @@ __global__ void __launch_bounds__(256) add_ln_mod_fwd_kernel(const T* __restrict
     for (int it = 0; it < MAX_IT; ++it) {
       const int d = it * 512 + lane * 8;
       if (it < nit && d < D) {
-        f32x8 xv = load8(x_in + off + d);
+        // x_in / y are read once and x_out is next read by the following LayerNorm, two GEMMs later: streaming
+        // (nontemporal) accesses for the three, so that they do not displace h, which the next GEMM reads right away
+        // (M = 196608: 150 -> 139 us)
+        f32x8 xv = load8_nt(x_in + off + d);
         if (y) {
-          f32x8 yv = load8(y + off + d), gv = load8(gate + (int64_t)b * mod_ld + d);
+          f32x8 yv = load8_nt(y + off + d), gv = load8(gate + (int64_t)b * mod_ld + d);
           xv = xv + gv * yv;
           // keep the stored residual stream and the normalised value consistent in reduced precision
           if constexpr (sizeof(T) == 2) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) xv[e] = (float)(bf16_t)xv[e];
           }
-          store8(x_out + off + d, xv);
+          store8_nt(x_out + off + d, xv);
         }
         v[it] = xv;
         _Pragma("unroll") for (int e = 0; e < 8; ++e) s += xv[e];
@@ -111,7 +133,9 @@ __global__ void __launch_bounds__(256) add_ln_mod_bwd_kernel(
     for (int it = 0; it < MAX_IT; ++it) {
       const int d = it * 512 + lane * 8;
       if (it < nit && d < D) {
-        f32x8 xv = load8(x + off + d), dv = load8(dh + off + d);
+        // streaming accesses for what is read once here (x, y, dx_in) and for dx_out (next read two GEMMs later); dh was
+        // just written by the previous GEMM and dy feeds the next one (M = 196608: 189 -> 177 us)
+        f32x8 xv = load8_nt(x + off + d), dv = load8(dh + off + d);
         f32x8 sc = scale ? load8(scale + (int64_t)b * mod_ld + d)
                          : (affine ? f32x8{1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f} : f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
 #pragma unroll
@@ -136,10 +160,10 @@ __global__ void __launch_bounds__(256) add_ln_mod_bwd_kernel(
         f32x8 dx;
 #pragma unroll
         for (int e = 0; e < 8; ++e) dx[e] = rstd * (g[it][e] - s1 - xh[it][e] * s2);
-        if (dx_in) dx = dx + load8(dx_in + off + d);
-        store8(dx_out + off + d, dx);
+        if (dx_in) dx = dx + load8_nt(dx_in + off + d);
+        store8_nt(dx_out + off + d, dx);
         if (y) {
-          f32x8 yv = load8(y + off + d), gv = load8(gate + (int64_t)b * mod_ld + d);
+          f32x8 yv = load8_nt(y + off + d), gv = load8(gate + (int64_t)b * mod_ld + d);
           store8(dy + off + d, gv * dx);
 #pragma unroll
           for (int e = 0; e < 8; ++e) a_g[it][e] += dx[e] * yv[e];
