@@ -23,7 +23,7 @@ import torch.distributed as dist  # noqa: E402
 
 MODEL = "DiT-S/2"
 # per-GPU batch: the config does not fix it (the reference yaml trains at 16); sweep on one MI355X:
-# 16 -> 3.6k, 64 -> 8.9k, 128 -> 11.7k, 256 -> 13.2k, 512 -> 14.0k, 768 -> 14.5k images/s.  768 = 33 GB of activations, and
+# 16 -> 3.6k, 64 -> 8.9k, 128 -> 11.7k, 256 -> 13.2k, 512 -> 14.1k, 768 -> 14.9k images/s.  768 = 33 GB of activations, and
 # M = 196608 token rows is a whole number of rounds of the one-workgroup-per-CU GEMM tiles (1024 x 192 rows, 768 x 256).
 DEFAULT_BATCH = 768
 # step GFLOP per image (3 x forward, no recompute)
