@@ -206,14 +206,17 @@ def rectified_flow_loss(
     prediction_type: Optional[str] = None,
     rescale_image=False,
     rescale_noise=False,
+    timesteps=None,
 ) -> LossOracleOut:
-    """``RectifiedFlowLoss.forward`` rectified_flow.py:63-96 with injected (noise, sigmas)."""
+    """``RectifiedFlowLoss.forward`` rectified_flow.py:63-96 with injected (noise, sigmas).  ``timesteps`` given =
+    ``time_sampling_type="uniform_timestep"`` (rectified_flow.py:32-33: integer timesteps, table sigmas)."""
     prediction_type = prediction_type or scheduler.config.prediction_type
     if rescale_image:  # rectified_flow.py:56-58
         x = x / x.std([1, 2, 3], keepdim=True) * 0.937
     if rescale_noise:  # :59-60
         noise = noise / noise.std([1, 2, 3], keepdim=True)
-    timesteps = sigma_to_timestep(scheduler, sigmas)
+    if timesteps is None:
+        timesteps = sigma_to_timestep(scheduler, sigmas)
     noisy = q_sample(x, noise, sigmas)  # :71
     out = model_fn(noisy, timesteps)
     target = noise - x  # :79

@@ -127,6 +127,31 @@ def gen_rf(rmod, name, shape, seed, **kw):
          dloss_dout=out.grad)
 
 
+def gen_rf_uniform_timestep(rmod, name, shape, seed, **kw):
+    """RectifiedFlowLoss(time_sampling_type="uniform_timestep") (rectified_flow.py:32-33): integer timesteps drawn as in
+    DiffusionLoss (diffusion.py:64-72), sigmas from the scheduler table; noise injected through the 5-D hook."""
+    B = shape[0]
+    torch.manual_seed(seed)
+    x = torch.randn(shape)
+    noise = torch.randn(shape)
+    out = torch.randn(shape, requires_grad=True)
+    sched = EulerDiscreteScheduler.sdxl(**({"prediction_type": kw.pop("model_prediction_type")} if "model_prediction_type" in kw else {}))
+    loss_mod = rmod.RectifiedFlowLoss(scheduler=sched, time_sampling_type="uniform_timestep", **kw)
+    unet = LeafUNet(out)
+    x5 = torch.stack([x, noise], dim=1)
+    torch.manual_seed(seed + 1)
+    loss, aux = loss_mod(x5, unet)
+    loss.backward()
+    torch.manual_seed(seed + 1)
+    t = torch.randint(0, sched.config.num_train_timesteps, (B,))  # the only draw (noise is injected)
+    assert torch.equal(t, aux.timesteps)
+    sig = loss_mod.get_sigmas_for_timesteps(t)
+    meta = dict(kind="rf_uniform_timestep", shape=list(shape), seed=seed, kwargs=kw, prediction_type=loss_mod.prediction_type)
+    save(name, meta, x=x, noise=noise, timesteps=t, sigmas=sig, model_output=out.detach(),
+         noisy=aux.noisy_latent, pred=aux.pred, target=aux.target, losses=aux.losses, loss=loss.detach(),
+         dloss_dout=out.grad)
+
+
 def gen_nnw(rmod, name, shape, seed, model_prediction_type="epsilon"):
     """NNWeightedRFLoss.forward (rectified_flow.py:154-203) with the toy loss-prediction module of tests/golden_util.py."""
     from tests.golden_util import ToyLossPred
@@ -154,6 +179,10 @@ def gen_nnw(rmod, name, shape, seed, model_prediction_type="epsilon"):
 def main():
     os.makedirs(OUT, exist_ok=True)
     dmod, rmod = load_reference_loss()
+    if "--rfut-only" in sys.argv:  # round 2 addition; leaves the round-1 fixtures untouched
+        gen_rf_uniform_timestep(rmod, "rfut_s0_epsilon", (4, 4, 8, 8), 0, model_prediction_type="epsilon")
+        gen_rf_uniform_timestep(rmod, "rfut_s1215_v_prediction", (4, 4, 8, 8), 1215, model_prediction_type="v_prediction")
+        return
     sched = EulerDiscreteScheduler.sdxl()
     lm = dmod.DiffusionLoss(sched)
     save("tables", dict(kind="tables"), all_snr=sched.all_snr, sigmas=sched.sigmas, timesteps=sched.timesteps,
@@ -177,6 +206,8 @@ def main():
     gen_diffusion(dmod, "dl_big_eps", big, 1215)
     gen_diffusion(dmod, "dl_big_eps_snr_debias", big, 1215, use_snr_weight=True, use_debiased_estimation=True)
     gen_rf(rmod, "rf_big_eps", big, 1215)
+    gen_rf_uniform_timestep(rmod, "rfut_s0_epsilon", small, 0, model_prediction_type="epsilon")
+    gen_rf_uniform_timestep(rmod, "rfut_s1215_v_prediction", small, 1215, model_prediction_type="v_prediction")
 
     gen_nnw(rmod, "nnw_s0_eps", small, 0)
     gen_nnw(rmod, "nnw_s1215_v", small, 1215, model_prediction_type="v_prediction")

@@ -43,6 +43,8 @@ if __name__ == "__main__":
     if "seed" in config:  # after model construction, as the reference does (weight init is not seeded)
         seed_everything(config.seed + trainer.global_rank)
     ckpt_path = config.get("resume_from_checkpoint", None)
+    if isinstance(ckpt_path, dict):  # the reference accepts an instantiable here (test_train.py:71-75)
+        ckpt_path = instantiate_any(ckpt_path)
     if ckpt_path is not None:
-        logger.info(f"Resume from {ckpt_path}... (not supported; ignored)")
-    trainer.fit(trainer_wrapper, data_module)
+        logger.info(f"Resume from {ckpt_path}...")
+    trainer.fit(trainer_wrapper, data_module, ckpt_path=ckpt_path)

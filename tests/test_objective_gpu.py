@@ -72,6 +72,29 @@ def test_rf_loss_vs_reference_golden(name):
     close(out.grad, d["dloss_dout"], rtol=5e-4, atol=1e-7)
 
 
+@pytest.mark.parametrize("name", names("rfut_"))
+def test_rf_uniform_timestep_vs_reference_golden(name):
+    """RectifiedFlowLoss(time_sampling_type="uniform_timestep") (reference rectified_flow.py:32-33)."""
+    from uwudiff_amd.objective import RectifiedFlowLoss
+
+    meta, d = load(name)
+    dev = "cuda"
+    mod = RectifiedFlowLoss(scheduler=_sched(prediction_type=meta["prediction_type"]),
+                            time_sampling_type="uniform_timestep", **meta["kwargs"])
+    out = d["model_output"].to(dev).requires_grad_(True)
+    mod.inject(timesteps=d["timesteps"].to(dev))
+    x5 = torch.stack([d["x"], d["noise"]], dim=1).to(dev)
+    loss, aux = mod(x5, LeafUNet(out))
+    loss.backward()
+    assert torch.equal(aux.timesteps.cpu(), d["timesteps"])
+    close(aux.noisy_latent, d["noisy"], rtol=1e-4, atol=1e-5)
+    close(aux.target, d["target"], rtol=1e-4, atol=1e-5)
+    close(aux.pred, d["pred"], rtol=2e-4, atol=2e-4)
+    close(aux.losses, d["losses"], rtol=2e-4, atol=1e-7)
+    close(loss, d["loss"], rtol=2e-4, atol=1e-7)
+    close(out.grad, d["dloss_dout"], rtol=5e-4, atol=1e-7)
+
+
 def test_sigma_to_timestep_golden():
     from uwudiff_amd import lib as L
     from uwudiff_amd.objective import RectifiedFlowLoss

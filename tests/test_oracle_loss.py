@@ -85,6 +85,22 @@ def test_rf_loss_golden(name):
     close(o.dloss_dout, d["dloss_dout"], rtol=2e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("name", names("rfut_"))
+def test_rf_uniform_timestep_golden(name):
+    """time_sampling_type="uniform_timestep" (reference rectified_flow.py:32-33), fixtures from the reference class."""
+    meta, d = load(name)
+    s = EulerDiscreteScheduler.sdxl(prediction_type=meta["prediction_type"])
+    sig = OL.sigmas_for_timesteps(s, d["timesteps"])
+    close(sig, d["sigmas"], rtol=0, atol=0)
+    o = OL.rectified_flow_loss(s, d["x"], d["noise"], sig, lambda n, t: d["model_output"], timesteps=d["timesteps"])
+    close(o.noisy_latent, d["noisy"])
+    close(o.target, d["target"])
+    close(o.pred, d["pred"], rtol=1e-5, atol=1e-5)
+    close(o.losses, d["losses"], rtol=1e-5, atol=1e-7)
+    close(o.loss, d["loss"], rtol=1e-5, atol=1e-7)
+    close(o.dloss_dout, d["dloss_dout"], rtol=2e-5, atol=1e-7)
+
+
 def test_sigma_to_timestep_golden():
     _, d = load("sigma_to_timestep")
     s = EulerDiscreteScheduler.sdxl()

@@ -3,7 +3,8 @@
 global-norm clipping, optimizer + per-step LR schedule, rank-aware seeding, periodic logging.
 
 Lightning's loop is third-party control plane; the hot path it drives (loss -> denoiser fwd/bwd -> all-reduce ->
-clip -> AdamW) is the part this build implements natively.
+clip -> AdamW) is the part this build implements natively.  Checkpoint / resume follow Lightning's file layout
+(``Fitter.save_checkpoint`` / ``fit(ckpt_path=...)``; the ``ModelCheckpoint`` callback of the YAMLs writes them).
 """
 import json
 import os
@@ -26,10 +27,46 @@ def seed_everything(seed: int):
 
 
 class ModelCheckpoint:
-    """Accepted for config compatibility (configs/demo_training.yaml:14-19); checkpointing is out of scope."""
+    """``lightning.pytorch.callbacks.ModelCheckpoint`` subset the reference configs use (configs/demo_training.yaml:14-19):
+    ``dirpath``, ``filename``, ``every_n_train_steps`` (or ``every_n_epochs``), ``save_last``.  Registered by
+    :meth:`Fitter.fit` as a step hook that calls :meth:`Fitter.save_checkpoint` (Lightning checkpoint layout)."""
 
-    def __init__(self, **kw):
+    def __init__(self, dirpath=None, filename=None, every_n_train_steps=None, every_n_epochs=None, save_last=False,
+                 save_top_k=None, **kw):
+        self.dirpath = dirpath or "checkpoints"
+        self.filename = filename or "step={step}"
+        self.every_n_train_steps = int(every_n_train_steps) if every_n_train_steps else None
+        self.every_n_epochs = int(every_n_epochs) if every_n_epochs else None
+        self.save_last = bool(save_last)
+        self.save_top_k = save_top_k  # monitor: step / mode: max (the reference YAML) == keep the newest k files
         self.kw = kw
+        self.saved = []
+
+    def _save(self, fitter, path):
+        fitter.save_checkpoint(path)
+        self.saved.append(path)
+        k = self.save_top_k
+        if k is not None and k > 0 and fitter.global_rank == 0:
+            while len(self.saved) > k:
+                old = self.saved.pop(0)
+                if os.path.exists(old):
+                    os.remove(old)
+
+    def _path(self, fitter, name=None):
+        name = name or self.filename.format(step=fitter.global_step, epoch=fitter.current_epoch)
+        return os.path.join(self.dirpath, name + ".ckpt")
+
+    def on_step(self, fitter):
+        if self.every_n_train_steps and fitter.global_step % self.every_n_train_steps == 0:
+            self._save(fitter, self._path(fitter))
+
+    def on_epoch_end(self, fitter):
+        if self.every_n_epochs and (fitter.current_epoch + 1) % self.every_n_epochs == 0:
+            self._save(fitter, self._path(fitter))
+
+    def on_fit_end(self, fitter):
+        if self.save_last:
+            fitter.save_checkpoint(self._path(fitter, "last"))
 
 
 class LearningRateMonitor:
@@ -60,6 +97,19 @@ class GradualWarmupScheduler:
         else:
             self._apply()
 
+    # resume (reference trainer.py:76-92 re-links the wrapped scheduler's optimizer on load; here both live in one state)
+    def state_dict(self):
+        after = self.after.state_dict() if self.after is not None and hasattr(self.after, "state_dict") else None
+        return {"n": self.n, "base": list(self.base), "total": self.total, "after": after,
+                "lr": [g["lr"] for g in self.optimizer.param_groups]}
+
+    def load_state_dict(self, sd):
+        self.n, self.base, self.total = int(sd["n"]), list(sd["base"]), sd["total"]
+        if sd.get("after") is not None and self.after is not None:
+            self.after.load_state_dict(sd["after"])
+        for g, lr in zip(self.optimizer.param_groups, sd["lr"]):  # the LR in force when the checkpoint was written
+            g["lr"] = lr
+
 
 def _dist_env():
     rank = int(os.environ.get("RANK", "0"))
@@ -80,12 +130,15 @@ class Fitter:
         self.max_epochs = max_epochs
         self.global_rank, self.world_size, self.local_rank = _dist_env()
         self.global_step = 0
+        self.current_epoch = 0
         self.history = []
         self.step_hooks = []  # callables(fitter) run after every optimizer step (e.g. periodic save_checkpoint)
+        self.callbacks = list(callbacks or [])
+        use_gpu = torch.cuda.is_available() and str(accelerator) != "cpu"
         if self.world_size > 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
-        if torch.cuda.is_available():
+            dist.init_process_group("nccl" if use_gpu else "gloo")
+        if use_gpu:
             torch.cuda.set_device(self.local_rank)
             self.device = torch.device("cuda", self.local_rank)
         else:
@@ -160,10 +213,22 @@ class Fitter:
         cfg = module.configure_optimizers()
         opt = cfg["optimizer"] if isinstance(cfg, dict) else cfg
         sched = cfg["lr_scheduler"]["scheduler"] if isinstance(cfg, dict) and "lr_scheduler" in cfg else None
-        sync = FlatGradSync(self.world_size).attach(module.unet)
+        fused = isinstance(opt, FusedAdamW)
+        sync = FlatGradSync(self.world_size)
+        if fused:  # the early (inside-backward) reduction is consumed by FusedAdamW's per-chunk waits only; a foreign
+            sync.attach(module.unet)  # optimizer takes the plain whole-buffer exchange below
+        elif hasattr(module.unet, "set_grad_ready_hook"):
+            module.unet.set_grad_ready_hook(None)
         self._fit_state = (module, opt, sched)
         if ckpt_path is not None:
             self.load_checkpoint(ckpt_path)
+        if self.world_size > 1 and hasattr(module.unet, "flat"):
+            # identical replicas (Lightning DDP broadcasts rank 0's module state): do not rely on per-rank seeding order
+            dist.broadcast(module.unet.flat.data, src=0)
+            if hasattr(module.unet, "refresh_shadow"):
+                module.unet.refresh_shadow()
+        # Lightning's fast_dev_run disables checkpoint callbacks and loggers
+        ckpt_cbs = [] if self.fast_dev_run else [cb for cb in self.callbacks if isinstance(cb, ModelCheckpoint)]
         params = [p for g in opt.param_groups for p in g["params"]]
         max_steps = 1 if self.fast_dev_run else self.max_steps
         t0 = time.time()
@@ -197,8 +262,9 @@ class Fitter:
                 else:  # foreign optimizer (e.g. lion): plain torch path on the flat buffer
                     for p in params:
                         if self.world_size > 1:
-                            dist.all_reduce(p.grad)
-                            p.grad.mul_(1.0 / self.world_size)
+                            sync.all_reduce(p.grad)  # same chunked exchange; nothing was reduced early (no hook)
+                            sync.wait_all()
+                            p.grad.mul_(sync.pre_scale)
                     if self.gradient_clip_val:
                         torch.nn.utils.clip_grad_norm_(params, self.gradient_clip_val)
                     opt.step()
@@ -209,18 +275,25 @@ class Fitter:
                 self.global_step += 1
                 for hook in self.step_hooks:
                     hook(self)
+                for cb in ckpt_cbs:
+                    cb.on_step(self)
                 if self.global_step % self.log_every_n_steps == 0 or self.fast_dev_run or done:
                     rec = {"step": self.global_step, "loss": float(loss.detach()), "ema_loss": float(module.ema_loss),
                            "lr": opt.param_groups[0]["lr"], "elapsed_s": round(time.time() - t0, 3)}
                     self.history.append(rec)
                     if self.global_rank == 0:
                         print(json.dumps(rec), flush=True)
+            for cb in ckpt_cbs:
+                cb.on_epoch_end(self)
             epoch += 1
+            self.current_epoch = epoch
             resume_skip = 0
             if self.max_epochs is not None and epoch >= self.max_epochs:
                 break
             if max_steps < 0 and self.max_epochs is None:
                 break  # one pass when neither bound is given
+        for cb in ckpt_cbs:
+            cb.on_fit_end(self)
         if self.device.type == "cuda":
             torch.cuda.synchronize()
         return self.history

@@ -52,8 +52,11 @@ class _FusedLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_loss, *_):
-        (grad,) = ctx.saved_tensors
-        g = g_loss.to(device=grad.device, dtype=torch.float32).contiguous()
+        (saved,) = ctx.saved_tensors
+        g = g_loss.to(device=saved.device, dtype=torch.float32).contiguous()
+        # scale a copy: a second backward through the same graph (retain_graph / accumulation helpers) must see the
+        # unscaled gradient again, and the returned tensor must not alias the saved one
+        grad = saved.clone()
         L.call("uwu_scale_inplace", L.ptr(grad), L.dt(grad), grad.numel(), L.ptr(g), L.stream())
         if grad.dtype != ctx.out_dtype:
             grad = grad.to(ctx.out_dtype)
