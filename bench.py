@@ -18,6 +18,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+import subprocess  # noqa: E402
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -83,6 +85,69 @@ def cpu_baseline(batch=16, warm=2, iters=5):  # B=16, median 
             "sample": f"oracle DiT-S/2 fp32 CPU, batch {batch}, median of {iters} steps (fwd+bwd+AdamW) after {warm} warm-ups"}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start one CHILD process per rank (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in its environment) and wait.  The parent never initialises the GPU and never exec()s; rank 0's stdout
+    (the one JSON line) is this process's stdout."""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                code = p.poll()
+                if code is None:
+                    continue
+                procs.remove(p)
+                if code != 0:  # one rank failed: the others would wait in a collective forever
+                    rc = rc or code
+                    for q in procs:
+                        q.terminate()
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            p.kill()
+    return rc
+
+
+# kernel families of the live profiler (include/uwu_hip.h UWU_PROF_*): (tag, name, bound)
+FAMILIES = [(0, "gemm_fwd (qkv / proj / fc2 forward)", "mfma"), (1, "gemm_dgrad (input gradients)", "mfma"),
+            (2, "gemm_wgrad (streaming weight gradients + split-K reduce)", "mfma"),
+            (3, "gemm fc1 + bias + GELU", "mfma"), (4, "gemm fc2 dgrad + dGELU", "mfma"),
+            (5, "attn_fwd_mfma", "mfma"), (6, "attn_bwd_mfma", "mfma"),
+            (7, "add_ln_mod_fwd", "hbm"), (8, "add_ln_mod_bwd", "hbm")]
+PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md "Chip-level parameters" (spec; 6.3 TB/s is what a copy reaches)
+
+
+def collect_families(L, lib, n_prof, kind):
+    """Per-family roofline entries from the live profiler: achieved = algorithmic FLOPs (or bytes) / measured duration."""
+    out = []
+    for tag, name, bound in FAMILIES:
+        ms, fl, by, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+        L.check(lib.uwu_prof_collect(tag, -1 if tag >= 5 else kind, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by),
+                                     ctypes.byref(n)), "prof_collect")
+        if not n.value or ms.value <= 0:
+            continue
+        sec = ms.value * 1e-3
+        e = {"kernel": name, "bound": bound, "launches_per_step": n.value // n_prof,
+             "avg_launch_us": round(ms.value * 1e3 / n.value, 2), "ms_per_step": round(ms.value / n_prof, 3),
+             "tflops": round(fl.value / sec / 1e12, 1), "gbs": round(by.value / sec / 1e9, 1)}
+        e["frac"] = round(e["tflops"] / PEAK_BF16_TFLOPS, 4) if bound == "mfma" else round(e["gbs"] / PEAK_HBM_GBS, 4)
+        e["frac_hbm"] = round(e["gbs"] / PEAK_HBM_GBS, 4)
+        out.append(e)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,6 +156,7 @@ def main():
     ap.add_argument("--batch", type=int, default=DEFAULT_BATCH, help="per-GPU batch (weak scaling)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the per-GPU batch sweep (16 / 64 / 256) after the timed region")
     ap.add_argument("--clip", type=float, default=0.0)
     ap.add_argument("--model", default=MODEL, choices=sorted(STEP_GFLOP),
                     help="denoiser; the headline metric (BASELINE.json) is DiT-S/2, the others are extra configs "
@@ -101,14 +167,14 @@ def main():
                          "multi-process path on a 1-GPU box")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))  # nothing in this process has touched the GPU yet
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: timing {world} rank(s)", file=sys.stderr)
     ndev = torch.cuda.device_count()
     local = local % max(ndev, 1) if args.backend == "gloo" else local
     torch.cuda.set_device(local)
@@ -155,24 +221,25 @@ def main():
     model.flat.grad = torch.zeros_like(model.flat.data)
     step_no = [0]
 
-    def step():
+    def step(b=B, sy=None):
+        sy = sy or sync
         i = step_no[0]
-        off = (i * B) % (pool_n - B + 1)
-        x, c = pool[off:off + B], pooled[off:off + B]
+        off = (i * b) % (pool_n - b + 1)
+        x, c = pool[off:off + b], pooled[off:off + b]
         model.flat.grad.zero_()
         if unet:
-            loss, _ = loss_fn(x, model, encoder_hidden_states=ctx, added_cond_kwargs={"text_embeds": c, "time_ids": time_ids})
+            loss, _ = loss_fn(x, model, encoder_hidden_states=ctx[:b], added_cond_kwargs={"text_embeds": c, "time_ids": time_ids[:b]})
         else:
             loss, _ = loss_fn(x, model, added_cond_kwargs={"text_embeds": c})
         loss.backward()
-        chunks = sync.all_reduce(model.flat.grad)
+        chunks = sy.all_reduce(model.flat.grad)
         opt.param_groups[0]["lr"] = cosine_lr(1e-6, i, 100_000, 1e-7)
         if args.clip > 0:
-            sync.wait_all()
-            clip = opt.grad_norm_clip(args.clip, pre_scale=sync.pre_scale)
-            opt.step(clip=clip, pre_scale=sync.pre_scale)
+            sy.wait_all()
+            clip = opt.grad_norm_clip(args.clip, pre_scale=sy.pre_scale)
+            opt.step(clip=clip, pre_scale=sy.pre_scale)
         else:
-            opt.step(pre_scale=sync.pre_scale, chunks=chunks, before_chunk=sync.wait_chunk)
+            opt.step(pre_scale=sy.pre_scale, chunks=chunks, before_chunk=sy.wait_chunk)
         step_no[0] += 1
         return loss
 
@@ -181,64 +248,107 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(n, **kw):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            loss = step(**kw)
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            te = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            el = te.item()
+        return el, loss
+
     if rank == 0:
         print(f"[bench] {args.model} {args.dtype} per-GPU batch {B} x {world} GPU(s): warm-up {args.warmup}, timing {args.steps} steps",
               file=sys.stderr, flush=True)
     for _ in range(args.warmup):
         step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = te.item()
+    elapsed, loss = timed(args.steps)
     final_loss = float(loss.detach())
     if rank == 0:
         print(f"[bench] timed region done: {elapsed / args.steps * 1e3:.3f} ms/step", file=sys.stderr, flush=True)
 
-    # ---- roofline of the dominant kernel (bf16 MFMA GEMM family): HIP events around every GEMM launch on the
-    # launch stream, over a replay of the same steps (instrumentation kept out of the throughput window)
+    # ---- N > 1: how much of the gradient exchange is NOT hidden = step time with the exchange - step time without it
+    # (same kernels, the all-reduce calls skipped; replicas drift apart afterwards, which no longer matters)
+    comm = None
+    if world > 1:
+        n_c = min(10, max(2, args.steps))
+        t_sync, _ = timed(n_c)
+        if hasattr(model, "set_grad_ready_hook"):
+            model.set_grad_ready_hook(None)
+        nosync = FlatGradSync(1)
+        t_nosync, _ = timed(n_c, sy=nosync)
+        comm = {"rccl_ranks": dist.get_world_size(), "backend": args.backend,
+                "ms_per_step_with_exchange": round(t_sync / n_c * 1e3, 3),
+                "ms_per_step_without_exchange": round(t_nosync / n_c * 1e3, 3),
+                "exposed_comm_ms": round((t_sync - t_nosync) / n_c * 1e3, 3),
+                "grad_bytes": int(model.flat.numel() * 4)}
+        sync_prof = nosync
+    else:
+        sync_prof = sync
+
+    # ---- roofline: HIP events around every instrumented launch on the launch stream, over a replay of the same
+    # steps (instrumentation kept out of the throughput window).  Dominant family = the bf16 MFMA GEMMs.
     roof = None
     if rank == 0:
         lib = L.load()
         n_prof = min(5, max(1, args.steps))
-        L.check(lib.uwu_gemm_prof_enable(1), "prof_enable")
+        L.check(lib.uwu_prof_enable(1), "prof_enable")
         for _ in range(n_prof):
-            step()
+            step(sy=sync_prof)
         torch.cuda.synchronize()
-        L.check(lib.uwu_gemm_prof_enable(0), "prof_disable")
+        L.check(lib.uwu_prof_enable(0), "prof_disable")
         ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
-        kind = 0 if args.dtype == "bf16" else 1
+        kind = 0 if args.dtype in ("bf16", "fp8") else 1
         L.check(lib.uwu_gemm_prof_collect(kind, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)), "prof_collect")
         if n.value:
             ach = fl.value / (ms.value * 1e-3) / 1e12
-            peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_BF16_TFLOPS / 16
+            peak = {"bf16": PEAK_BF16_TFLOPS, "fp8": 2 * PEAK_BF16_TFLOPS, "fp32": PEAK_BF16_TFLOPS / 16}[args.dtype]
             # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this
-            # same command, gfx950 corrections applied by tools/summarize_pmc.py); null if not collected
-            traffic = None
-            tj = os.path.join(ROOT, "profiles", "r01_pmc_gemm_traffic.json")
+            # same command, gfx950 corrections applied by tools/summarize_pmc.py).  The file names the kernel source
+            # it was measured on; a number from other kernels is not reported.
+            traffic, traffic_src = None, None
+            tj = os.path.join(ROOT, "profiles", "r02_pmc_gemm_traffic.json")
             if args.dtype == "bf16" and B == DEFAULT_BATCH and args.model == MODEL and os.path.exists(tj):
                 with open(tj) as f:
-                    traffic = round(json.load(f)["hbm_bytes_per_launch"])
+                    tjd = json.load(f)
+                if tjd.get("gemm_src_sha16") == src_sha16():
+                    traffic = round(tjd["hbm_bytes_per_launch"])
+                    traffic_src = "profiles/r02_pmc_gemm_traffic.json (separate --pmc passes over this command, same gemm.hip)"
             roof = {"bound": "mfma", "kernel": "bf16 MFMA GEMM family (gemm_kernel / gemm_r3_kernel / gemm_big_kernel / gemm_wide_kernel / gemm_tr_kernel, v_mfma_f32_16x16x32_bf16; fwd+dgrad+wgrad launches)",
                     "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": traffic, "launches_per_step": n.value // n_prof,
+                    "traffic": traffic, "traffic_source": traffic_src, "launches_per_step": n.value // n_prof,
                     "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
-                    "gemm_ms_per_step": round(ms.value / n_prof, 3)}
+                    "gemm_ms_per_step": round(ms.value / n_prof, 3),
+                    "kernels": collect_families(L, lib, n_prof, kind)}
     elif world > 1:
         for _ in range(min(5, max(1, args.steps))):
-            step()
+            step(sy=sync_prof)
         torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
 
+    # ---- per-GPU batch sweep (the reference yaml's 16, and 64 / 256), N = 1 only, short
+    sweep = None
+    if rank == 0 and world == 1 and not unet and not args.no_sweep:
+        sweep = {}
+        for b in (16, 64, 256):
+            if b == B:
+                continue
+            for _ in range(5):
+                step(b=b)
+            n_s = 30 if b <= 64 else 15
+            el, _ = timed(n_s, b=b)
+            sweep[str(b)] = round(b * n_s / el, 1)
+        sweep[str(B)] = round(B * args.steps / elapsed, 1)
+
     if rank == 0:
         imgs = B * world * args.steps
         value = imgs / elapsed
+        peak_chip = (2 * PEAK_BF16_TFLOPS if args.dtype == "fp8" else PEAK_BF16_TFLOPS)
         line = {
             "metric": f"train images/sec (whole node), {args.model} {'256^2 latent' if args.latent == 32 else '4x128x128 latents'}", "value": round(value, 1),
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -249,9 +359,11 @@ def main():
                        "per_gpu_batch": B, "global_batch": B * world, "tokens_per_image": None if unet else 256,
                        "parallelism": f"dp{world}"},
             "model_tflops": round(value * step_gflop / 1e3, 1),
-            "mfma_frac_whole_step": round(value * step_gflop / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
+            "mfma_frac_whole_step": round(value * step_gflop / 1e3 / (peak_chip * world), 4),
             "final_loss": round(final_loss, 5),
             "roofline": roof,
+            "batch_sweep": sweep,
+            "comm": comm,
         }
         if not args.no_cpu_baseline and world == 1 and args.model == MODEL:
             line["cpu_baseline"] = cpu_baseline()
@@ -260,6 +372,13 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def src_sha16():
+    import hashlib
+
+    with open(os.path.join(ROOT, "uwudiff_amd", "csrc", "gemm.hip"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
 if __name__ == "__main__":

@@ -170,6 +170,18 @@ int uwu_gemm_wgrad(const void* A, const void* B, float* C, float* bias_grad, int
 int uwu_gemm_prof_enable(int on);
 int uwu_gemm_prof_collect(int kind, double* ms, double* flops, int* launches);
 
+/* The same, per kernel family (measurement harness): tag = one of UWU_PROF_* (or < 0: all GEMM
+ * tags), kind 0 = bf16 / fp8 operands, 1 = fp32, < 0 = any.  flops / bytes are the ALGORITHMIC work of the recorded
+ * launches (GEMM 2*M*N*K and operands + outputs once; attention 4*T*Tk*d per head forward, x2.5 backward, and
+ * q/k/v/o (+ gradients) once; LayerNorm: every tensor it reads or writes once). */
+enum {
+  UWU_PROF_GEMM_FWD = 0, UWU_PROF_GEMM_DGRAD = 1, UWU_PROF_GEMM_WGRAD = 2, UWU_PROF_GEMM_FC1_GELU = 3,
+  UWU_PROF_GEMM_FC2_DGELU = 4, UWU_PROF_ATTN_FWD = 5, UWU_PROF_ATTN_BWD = 6, UWU_PROF_LN_FWD = 7, UWU_PROF_LN_BWD = 8,
+  UWU_PROF_CONV = 9, UWU_PROF_OTHER = 10
+};
+int uwu_prof_enable(int on);
+int uwu_prof_collect(int tag, int kind, double* ms, double* flops, double* bytes, int* launches);
+
 /* out[n] (+)= sum_m X[m,n]   (bias gradients). accumulate: 0 overwrite, 1 add. */
 int uwu_colsum(const void* X, int dtype, int M, int N, int ldx, float* out, int accumulate, void* stream);
 /* batched: out[b, n] (+)= sum_m X[b, m, n] for `batch` contiguous [M, ldx] slabs. */

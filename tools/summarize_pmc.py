@@ -4,7 +4,9 @@ MI355X_MICROARCH.md section HBM: FETCH_SIZE / WRITE_SIZE are in KiB (x1024); on 
 the bytes of a wide coalesced streaming read -> doubled.  WRITE_SIZE is exact for 16-B/lane stores and fp32 atomics."""
 import csv
 import glob
+import hashlib
 import json
+import os
 import sys
 
 
@@ -30,7 +32,9 @@ def load(dirname, counter):
 
 fetch, nf, pf = load(sys.argv[1], "FETCH_SIZE")
 write, nw, pw = load(sys.argv[2], "WRITE_SIZE")
+_src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "uwudiff_amd", "csrc", "gemm.hip")
 out = {
+    "gemm_src_sha16": hashlib.sha256(open(_src, "rb").read()).hexdigest()[:16],  # bench.py reports the number only for this source
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline",
     "kernel_family": "bf16 MFMA GEMM family: gemm_kernel / gemm_r3_kernel / gemm_big_kernel / gemm_wide_kernel / gemm_tr_kernel (+ splitk_reduce bytes), fwd + dgrad + wgrad launches",
     "launches": nf,

@@ -343,8 +343,13 @@ static int attention_fwd_impl(const void* q, const void* k, const void* v, void*
   UWU_CHECK_ARG(o && lse, "attention_fwd: null output");
   UWU_CHECK_ARG(scale > 0.f, "attention: scale must be positive");
   if (dtype == UWU_BF16 && !force_simple() && uwu_attn_mfma_fwd_ok(Tq, Tk, d, ldq, ldk, ldv, ldo) &&
-      (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0)
-    return uwu_attn_mfma_fwd(q, k, v, o, lse, kbias, B, Tq, Tk, H, d, ldq, ldk, ldv, ldo, scale, (hipStream_t)stream);
+      (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0) {
+    UwuProfScope prof(stream);
+    rc = uwu_attn_mfma_fwd(q, k, v, o, lse, kbias, B, Tq, Tk, H, d, ldq, ldk, ldv, ldo, scale, (hipStream_t)stream);
+    // algorithmic work: QK^T + PV = 4 Tq Tk d per head; q, o and k, v once (bf16)
+    prof.done(UWU_PROF_ATTN_FWD, 0, 4.0 * B * H * Tq * Tk * d, 2.0 * B * H * d * (2.0 * Tq + 2.0 * Tk));
+    return rc;
+  }
   AttnArgs a{};
   a.q = q; a.k = k; a.v = v; a.out = o; a.lse = lse; a.kbias = kbias;
   a.B = B; a.Tq = Tq; a.Tk = Tk; a.H = H; a.d = d; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
@@ -362,9 +367,14 @@ static int attention_bwd_impl(const void* q, const void* k, const void* v, const
   UWU_CHECK_ARG(scale > 0.f, "attention: scale must be positive");
   if (dtype == UWU_BF16 && !force_simple() && uwu_attn_mfma_bwd_ok(Tq, Tk, d, ldq, ldk, ldv, ldo) &&
       (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)dO | (uintptr_t)dq | (uintptr_t)dk |
-        (uintptr_t)dv) & 15) == 0)
-    return uwu_attn_mfma_bwd(q, k, v, o, dO, lse, delta, kbias, dq, dk, dv, B, Tq, Tk, H, d, ldq, ldk, ldv, ldo, scale,
-                             (hipStream_t)stream);
+        (uintptr_t)dv) & 15) == 0) {
+    UwuProfScope prof(stream);
+    rc = uwu_attn_mfma_bwd(q, k, v, o, dO, lse, delta, kbias, dq, dk, dv, B, Tq, Tk, H, d, ldq, ldk, ldv, ldo, scale,
+                           (hipStream_t)stream);
+    // five products (S, dP, dV, dK, dQ) = 10 Tq Tk d per head; q, o, dO, dq and k, v, dk, dv once (bf16)
+    prof.done(UWU_PROF_ATTN_BWD, 0, 10.0 * B * H * Tq * Tk * d, 2.0 * B * H * d * (4.0 * Tq + 4.0 * Tk));
+    return rc;
+  }
   AttnArgs a{};
   a.q = q; a.k = k; a.v = v; a.o = o; a.dO = dO; a.lse = const_cast<float*>(lse); a.delta = delta; a.dq = dq; a.dk = dk; a.dv = dv;
   a.kbias = kbias;

@@ -36,6 +36,18 @@ void uwu_set_error(const char* fmt, ...);
     }                                                                           \
   } while (0)
 
+// ---- live profiler hooks (prof.cpp) ------------------------------------------------------
+int uwu_prof_begin(void* stream);
+void uwu_prof_end(int slot, int tag, int kind, double flops, double bytes, void* stream);
+struct UwuProfScope {
+  int slot;
+  void* st;
+  explicit UwuProfScope(void* s) : slot(uwu_prof_begin(s)), st(s) {}
+  void done(int tag, int kind, double flops, double bytes) {
+    if (slot >= 0) uwu_prof_end(slot, tag, kind, flops, bytes, st);
+  }
+};
+
 // ---- scalar conversions -----------------------------------------------------------------
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }

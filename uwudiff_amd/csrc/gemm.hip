@@ -1246,17 +1246,21 @@ __global__ void __launch_bounds__(256, 2) gemm_tr_kernel(const GemmArgs g) {
     }
 }
 
-// ---- live profiler: HIP event pairs around GEMM launches on the launch stream (bench.py `roofline`) -------
-struct GemmProf {
-  static constexpr int MAXP = 8192;
-  bool on = false;
-  int n = 0;
-  hipEvent_t ev[2 * MAXP];
-  bool created = false;
-  double flops[MAXP];
-  int kind[MAXP];  // 0 = bf16 operands, 1 = fp32 operands
-};
-GemmProf g_prof;
+// ---- live profiler (prof.cpp): HIP event pairs around launches on the launch stream (bench.py `roofline`) -------
+// tag of a GEMM launch: forward / input gradient / weight gradient, the two GELU Linears apart
+static int gemm_tag(const GemmArgs& g, bool tb, bool acc) {
+  if (acc) return UWU_PROF_GEMM_WGRAD;
+  if (g.epi == UWU_EPI_BIAS_GELU) return UWU_PROF_GEMM_FC1_GELU;
+  if (g.epi == UWU_EPI_DGELU) return UWU_PROF_GEMM_FC2_DGELU;
+  return tb ? UWU_PROF_GEMM_DGRAD : UWU_PROF_GEMM_FWD;
+}
+// algorithmic bytes: both operands once, the output once (+ the second output / the aux operand of the GELU epilogues)
+static double gemm_bytes(const GemmArgs& g, int es, int esc) {
+  double b = ((double)g.M * g.K + (double)g.N * g.K) * es + (double)g.M * g.N * esc;
+  if (g.epi == UWU_EPI_BIAS_GELU || g.epi == UWU_EPI_BIAS_SILU) b += (double)g.M * g.N * esc;
+  if (g.epi == UWU_EPI_DGELU) b += (double)g.M * g.N * es;
+  return b;
+}
 
 template <typename T, typename TC, bool TA, bool TB, bool ACC, bool GL = false, int EPI = -1>
 int launch(const GemmArgs& g, int split, hipStream_t st) {
@@ -1268,15 +1272,9 @@ int launch(const GemmArgs& g, int split, hipStream_t st) {
     attr_done = true;
   }
   dim3 grid(g.tiles_m * g.tiles_n, 1, split);
-  const bool rec = g_prof.on && g_prof.n < GemmProf::MAXP;
-  if (rec) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], st);
+  UwuProfScope prof(st);
   hipLaunchKernelGGL(kern, grid, dim3(256), 4 * TILE_BYTES, st, g);
-  if (rec) {
-    (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st);
-    g_prof.flops[g_prof.n] = 2.0 * g.M * g.N * g.K;
-    g_prof.kind[g_prof.n] = sizeof(T) == 2 ? 0 : 1;
-    ++g_prof.n;
-  }
+  prof.done(gemm_tag(g, TB, ACC), sizeof(T) == 2 ? 0 : 1, 2.0 * g.M * g.N * g.K, gemm_bytes(g, sizeof(T), sizeof(TC)));
   UWU_LAUNCH_CHECK("gemm");
   return UWU_OK;
 }
@@ -1292,15 +1290,9 @@ int launch_r3(GemmArgs g, hipStream_t st) {
   }
   g.tiles_m = (g.M + 32 * FI - 1) / (32 * FI);
   g.tiles_n = (g.N + 127) / 128;
-  const bool rec = g_prof.on && g_prof.n < GemmProf::MAXP;
-  if (rec) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], st);
+  UwuProfScope prof(st);
   hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(256), LDS, st, g);
-  if (rec) {
-    (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st);
-    g_prof.flops[g_prof.n] = 2.0 * g.M * g.N * g.K;
-    g_prof.kind[g_prof.n] = 0;
-    ++g_prof.n;
-  }
+  prof.done(gemm_tag(g, TB, false), 0, 2.0 * g.M * g.N * g.K, gemm_bytes(g, 2, sizeof(TC)));
   UWU_LAUNCH_CHECK("gemm_r3");
   return UWU_OK;
 }
@@ -1315,15 +1307,9 @@ int launch_big(GemmArgs g, hipStream_t st) {
   }
   g.tiles_m = (g.M + 255) / 256;
   g.tiles_n = (g.N + 255) / 256;
-  const bool rec = g_prof.on && g_prof.n < GemmProf::MAXP;
-  if (rec) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], st);
+  UwuProfScope prof(st);
   hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(512), LDS, st, g);
-  if (rec) {
-    (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st);
-    g_prof.flops[g_prof.n] = 2.0 * g.M * g.N * g.K;
-    g_prof.kind[g_prof.n] = 0;
-    ++g_prof.n;
-  }
+  prof.done(gemm_tag(g, TB, false), 0, 2.0 * g.M * g.N * g.K, gemm_bytes(g, 2, sizeof(TC)));
   UWU_LAUNCH_CHECK("gemm_big");
   return UWU_OK;
 }
@@ -1333,15 +1319,9 @@ int launch_m64(GemmArgs g, hipStream_t st) {
   constexpr int LDS = 2 * (64 * ROW_BYTES + TILE_BYTES);
   g.tiles_m = (g.M + 63) / 64;
   g.tiles_n = (g.N + 127) / 128;
-  const bool rec = g_prof.on && g_prof.n < GemmProf::MAXP;
-  if (rec) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], st);
+  UwuProfScope prof(st);
   hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(256), LDS, st, g);
-  if (rec) {
-    (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st);
-    g_prof.flops[g_prof.n] = 2.0 * g.M * g.N * g.K;
-    g_prof.kind[g_prof.n] = 0;
-    ++g_prof.n;
-  }
+  prof.done(gemm_tag(g, TB, false), 0, 2.0 * g.M * g.N * g.K, gemm_bytes(g, 2, sizeof(TC)));
   UWU_LAUNCH_CHECK("gemm_m64");
   return UWU_OK;
 }
@@ -1365,15 +1345,9 @@ int launch_wide(GemmArgs g, hipStream_t st) {
   }
   g.tiles_m = (g.M + 191) / 192;
   g.tiles_n = g.N / 384;
-  const bool rec = g_prof.on && g_prof.n < GemmProf::MAXP;
-  if (rec) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], st);
+  UwuProfScope prof(st);
   hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(512), LDS, st, g);
-  if (rec) {
-    (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st);
-    g_prof.flops[g_prof.n] = 2.0 * g.M * g.N * g.K;
-    g_prof.kind[g_prof.n] = 0;
-    ++g_prof.n;
-  }
+  prof.done(gemm_tag(g, TB, false), 0, 2.0 * g.M * g.N * g.K, gemm_bytes(g, 2, sizeof(TC)));
   UWU_LAUNCH_CHECK("gemm_wide");
   return UWU_OK;
 }
@@ -1445,8 +1419,7 @@ int launch_tr(GemmArgs g, void* scratch, size_t scratch_bytes, hipStream_t st) {
   // scratch path needs 16-byte rows in the scratch and in C
   const bool part = scratch && split > 1 && g.N % 4 == 0 && g.ldc % 4 == 0 && (((uintptr_t)g.C | (uintptr_t)scratch) & 15) == 0 &&
                     scratch_bytes >= (size_t)split * g.M * g.N * sizeof(float);
-  const bool rec = g_prof.on && g_prof.n < GemmProf::MAXP;
-  if (rec) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], st);
+  UwuProfScope prof(st);
   if (part) {
     g.C2 = scratch;
     hipLaunchKernelGGL((gemm_tr_kernel<FI, FJ, true>), dim3(grid), dim3(256), T_NST * T_STAGE, st, g);
@@ -1458,12 +1431,7 @@ int launch_tr(GemmArgs g, void* scratch, size_t scratch_bytes, hipStream_t st) {
   } else {
     hipLaunchKernelGGL((gemm_tr_kernel<FI, FJ, false>), dim3(grid), dim3(256), T_NST * T_STAGE, st, g);
   }
-  if (rec) {
-    (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st);
-    g_prof.flops[g_prof.n] = 2.0 * g.M * g.N * g.K;
-    g_prof.kind[g_prof.n] = 0;
-    ++g_prof.n;
-  }
+  prof.done(UWU_PROF_GEMM_WGRAD, 0, 2.0 * g.M * g.N * g.K, ((double)g.M * g.K + (double)g.N * g.K) * 2 + (double)g.M * g.N * 4);
   UWU_LAUNCH_CHECK("gemm_tr");
   return UWU_OK;
 }
@@ -1697,39 +1665,4 @@ extern "C" int uwu_gemm_wgrad(const void* A, const void* B, float* C, float* bia
                   split, stream);
 }
 
-// Enable/disable recording of a HIP event pair around every uwu_gemm launch (on that launch's stream).
-extern "C" int uwu_gemm_prof_enable(int on) {
-  if (on && !g_prof.created) {
-    for (int i = 0; i < 2 * GemmProf::MAXP; ++i)
-      if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) {
-        uwu_set_error("gemm_prof: hipEventCreate failed");
-        return UWU_ELAUNCH;
-      }
-    g_prof.created = true;
-  }
-  g_prof.on = on != 0;
-  if (on) g_prof.n = 0;
-  return UWU_OK;
-}
-// Sum of launch durations (ms), algorithmic FLOPs (2*M*N*K) and launch count for operand kind (0 bf16, 1 fp32)
-// since the last enable; waits for the recorded events (host-side, outside any timed region).
-extern "C" int uwu_gemm_prof_collect(int kind, double* ms, double* flops, int* launches) {
-  double t = 0.0, f = 0.0;
-  int c = 0;
-  for (int i = 0; i < g_prof.n; ++i) {
-    if (g_prof.kind[i] != kind) continue;
-    float e = 0.f;
-    if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess ||
-        hipEventElapsedTime(&e, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) {
-      uwu_set_error("gemm_prof: event query failed");
-      return UWU_ELAUNCH;
-    }
-    t += e;
-    f += g_prof.flops[i];
-    ++c;
-  }
-  if (ms) *ms = t;
-  if (flops) *flops = f;
-  if (launches) *launches = c;
-  return UWU_OK;
-}
+// (the profiler entry points live in prof.cpp: uwu_prof_enable / uwu_prof_collect; uwu_gemm_prof_* wrap them)

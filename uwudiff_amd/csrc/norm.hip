@@ -234,6 +234,7 @@ extern "C" int uwu_add_ln_modulate_fwd(const void* x_in, const void* y, const fl
   if (grid > 8192) grid = 8192;
   hipStream_t st = (hipStream_t)stream;
   UWU_CHECK_ARG(dtype == UWU_F32 || dtype == UWU_BF16, "add_ln_modulate_fwd: bad dtype");
+  UwuProfScope prof(stream);
 #define FWD_CASE(NIT)                                                                                              \
   case NIT:                                                                                                        \
     if (dtype == UWU_F32)                                                                                          \
@@ -249,6 +250,10 @@ extern "C" int uwu_add_ln_modulate_fwd(const void* x_in, const void* y, const fl
     FWD_CASE(1) FWD_CASE(2) FWD_CASE(3) FWD_CASE(4) FWD_CASE(5) FWD_CASE(6) FWD_CASE(7) FWD_CASE(8)
   }
 #undef FWD_CASE
+  {  // algorithmic bytes: x (+ y) read, h (+ x_out) written
+    const double e = dtype == UWU_BF16 ? 2.0 : 4.0, md = (double)M * D;
+    prof.done(UWU_PROF_LN_FWD, dtype == UWU_BF16 ? 0 : 1, 8.0 * md, md * e * (2 + (y ? 1 : 0) + (x_out && x_out != x_in ? 1 : 0)));
+  }
   UWU_LAUNCH_CHECK("add_ln_modulate_fwd");
   return UWU_OK;
 }
@@ -272,6 +277,7 @@ extern "C" int uwu_add_ln_modulate_bwd(const void* dh, const void* x, const floa
   hipStream_t st = (hipStream_t)stream;
   UWU_CHECK_ARG(dtype == UWU_F32 || dtype == UWU_BF16, "add_ln_modulate_bwd: bad dtype");
   UWU_CHECK_ARG(lds <= 160 * 1024, "add_ln_modulate_bwd: D=%d needs %zu B of LDS (> 160 KB)", D, lds);
+  UwuProfScope prof(stream);
 #define BWD_CASE(NIT)                                                                                               \
   case NIT:                                                                                                         \
     if (lds > 64 * 1024) { /* above the default dynamic-LDS limit: raise it once per instantiation */              \
@@ -300,6 +306,10 @@ extern "C" int uwu_add_ln_modulate_bwd(const void* dh, const void* x, const floa
       UWU_CHECK_ARG(false, "add_ln_modulate_bwd: D=%d > 3072 not instantiated", D);
   }
 #undef BWD_CASE
+  {  // algorithmic bytes: dh, x (+ dx_in, y) read, dx_out (+ dy) written
+    const double e = dtype == UWU_BF16 ? 2.0 : 4.0, md = (double)M * D;
+    prof.done(UWU_PROF_LN_BWD, dtype == UWU_BF16 ? 0 : 1, 16.0 * md, md * e * (3 + (dx_in ? 1 : 0) + (y ? 2 : 0)));
+  }
   UWU_LAUNCH_CHECK("add_ln_modulate_bwd");
   return UWU_OK;
 }

@@ -59,6 +59,8 @@ _SIGS = {
     "uwu_gemm_wgrad": (c_int, [P, P, P, P] + [c_int] * 8 + [P, ctypes.c_size_t, P]),
     "uwu_gemm_prof_enable": (c_int, [c_int]),
     "uwu_gemm_prof_collect": (c_int, [c_int, P, P, P]),
+    "uwu_prof_enable": (c_int, [c_int]),
+    "uwu_prof_collect": (c_int, [c_int, c_int, P, P, P, P]),
     "uwu_colsum": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, P]),
     "uwu_colsum_batched": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, P]),
     "uwu_add_ln_modulate_fwd": (c_int, [P, P, P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_float, c_int, c_int, P]),
