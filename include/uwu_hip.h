@@ -150,6 +150,32 @@ int uwu_gemm(const void* A, const void* B, void* C, void* C2, const float* bias,
              int M, int N, int K, int lda, int ldb, int ldc, int ldaux, int transA, int transB, int dtype,
              int c_dtype, int epilogue, int split_k, void* stream);
 
+/* fp8 operands (OCP e4m3 / e5m2, BASELINE.json config 5 "fp8 MFMA GEMMs"; the reference has no fp8 path -- its
+ * Linear is nn.Linear under bf16 autocast, rope_unet.py:122-166, demo_training_latent.yaml:6):
+ *   C[M,N] = (A[M,K] . B[N,K]^T) / (scale_a * scale_b)  (+ epilogue), both operands contraction-contiguous fp8 bytes,
+ * v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (2x the bf16 MFMA rate), fp32 accumulate.
+ * A has element format fmt_a (UWU_FP8_E4M3 or UWU_FP8_E5M2: output gradients), B is e4m3.  scale_a / scale_b: device
+ * floats, the per-tensor quantisation scales (x_fp8 = x * scale).  Epilogues NONE / BIAS / BIAS_GELU / DGELU write
+ * bf16 C (C2, aux bf16 as in uwu_gemm); UWU_EPI_ACCUM adds into fp32 C through split-K partial sums in `scratch`
+ * (uwu_gemm_fp8_scratch_bytes).  K % 128 == 0, leading dimensions multiples of 16 bytes. */
+#define UWU_FP8_E4M3 0
+#define UWU_FP8_E5M2 1
+size_t uwu_gemm_fp8_scratch_bytes(int M, int N, int K);
+int uwu_gemm_fp8(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux, int M, int N,
+                 int K, int lda, int ldb, int ldc, int ldaux, int fmt_a, int epilogue, const float* scale_a,
+                 const float* scale_b, void* scratch, size_t scratch_bytes, void* stream);
+
+/* Per-tensor fp8 quantisation (quant.hip).  amax: device float, max |x| is folded in with an atomic max (caller zeroes
+ * it, or uwu_fp8_update_scales does).  update_scales: scale[i] = FMT_MAX(fmt[i]) / (amax[i] * margin) where amax[i] > 0
+ * (otherwise the previous scale, or 1), then amax[i] = 0 -- the "delayed scaling" step between two training steps, or
+ * the second half of just-in-time scaling.  quantize: one pass over x [M,K] (bf16 / fp32, row-major, ldx) writing any
+ * of out [M,K] (ldo), out_t [K,M] (ldt; the operand layout of a contraction over M), colsum[K] += column sums of x
+ * (fp32 atomics; a bias gradient), amax.  Values are saturated to the format's largest finite number. */
+int uwu_fp8_amax(const void* x, int dtype, int64_t n, float* amax, void* stream);
+int uwu_fp8_update_scales(float* amax, float* scale, const int* fmt, int n, float margin, void* stream);
+int uwu_fp8_quantize(const void* x, int dtype, int M, int K, int ldx, const float* scale, int fmt, void* out, int ldo,
+                     void* out_t, int ldt, float* amax, float* colsum, void* stream);
+
 /* Weight gradient of a Linear with caller-provided split-K scratch:  C[M,N] (fp32) += A[K,M]^T . B[K,N], both
  * operands K-major (A = dY [tokens, out], B = X [tokens, in]; reference: autograd of nn.Linear inside the blocks,
  * rope_unet.py:122-166).  bf16 operands with K % 32 == 0 run the streaming kernel (LDS-DMA + transposing LDS

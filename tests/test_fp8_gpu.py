@@ -1,0 +1,138 @@
+"""fp8 (OCP e4m3 / e5m2) path of BASELINE config 5: the quantising kernels and the block-scaled-MFMA GEMM.
+
+Checker: fp32 CPU matmul on operands de-quantised with ``torch.float8_e4m3fn`` / ``torch.float8_e5m2`` (the reference
+has no fp8 path; its Linear is nn.Linear under bf16 autocast).  Exact on integer-valued operands (this also pins the
+lane -> k mapping of v_mfma_scale_f32_16x16x128_f8f6f4 for both operands), tolerance on random data.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+F8 = {0: torch.float8_e4m3fn, 1: torch.float8_e5m2}
+FMAX = {0: 448.0, 1: 57344.0}
+
+
+def deq(u8, fmt):
+    return u8.cpu().view(F8[fmt]).float()
+
+
+def ref_quant(x, s, fmt):
+    return (x.float().cpu() * s).clamp(-FMAX[fmt], FMAX[fmt]).to(F8[fmt])
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,K", [(64, 64), (200, 136), (1024, 1152)])
+def test_quantize_matches_torch_float8(fmt, dtype, M, K):
+    from uwudiff_amd import ops
+
+    torch.manual_seed(M + K + fmt)
+    x = (torch.randn(M, K) * 3).to(dtype)
+    x[0, 0] = 1e6  # saturates
+    x[1, 1] = -1e6
+    xd = x.cuda()
+    scale = torch.tensor([7.25], device="cuda")
+    amax = torch.zeros(1, device="cuda")
+    cs = torch.zeros(K, device="cuda")
+    Mp = (M + 15) // 16 * 16
+    out, _ = ops.fp8_quantize(xd, scale, fmt, amax=amax, colsum=cs)
+    want = ref_quant(x, 7.25, fmt)
+    assert torch.equal(out.cpu().view(F8[fmt]).view(torch.uint8), want.view(torch.uint8))
+    if M % 16 == 0:
+        _, out_t = ops.fp8_quantize(xd, scale, fmt, rowmajor=False, transposed=True)
+        assert torch.equal(out_t.cpu(), want.view(torch.uint8).t().contiguous())
+    assert float(amax) == float(x.float().abs().max())
+    torch.testing.assert_close(cs.cpu(), x.float().sum(0), rtol=1e-4, atol=1e-2 * 1e6 * 1e-4)
+    a2 = ops.fp8_amax(xd)
+    assert float(a2) == float(x.float().abs().max())
+
+
+def test_update_scales_policy():
+    from uwudiff_amd import ops
+
+    amax = torch.tensor([2.0, 0.0, 4.0], device="cuda")
+    scale = torch.tensor([0.0, 3.0, 1.0], device="cuda")
+    fmt = torch.tensor([0, 0, 1], device="cuda", dtype=torch.int32)
+    ops.fp8_update_scales(amax, scale, fmt)
+    assert scale.tolist() == [224.0, 3.0, 14336.0] and amax.tolist() == [0.0, 0.0, 0.0]
+
+
+@pytest.mark.parametrize("fmt_a", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 264, 384), (1024, 1152, 1152), (512, 4608, 1152)])
+def test_gemm_fp8_exact_on_integers(fmt_a, M, N, K):
+    """Small integers are exact in both formats and in the fp32 accumulator: any lane / k-permutation mismatch between the
+    two operands, a swapped output orientation or a wrong scale shows up as a wrong integer."""
+    from uwudiff_amd import ops
+
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a = torch.randint(-3, 4, (M, K), generator=g).float()
+    b = torch.randint(-2, 3, (N, K), generator=g).float()
+    a[:, ::7] = 0  # asymmetric sparsity pattern along k
+    b[::5] = 1.0
+    sa, sb = torch.tensor([2.0], device="cuda"), torch.tensor([0.5], device="cuda")
+    a8, _ = ops.fp8_quantize(a.cuda(), sa, fmt_a)
+    b8, _ = ops.fp8_quantize(b.cuda(), sb, 0)
+    c = ops.gemm_fp8(a8, b8, sa, sb, fmt_a=fmt_a)
+    want = (a @ b.t())
+    assert want.abs().max() < 256  # exactly representable in bf16
+    assert torch.equal(c.float().cpu(), want)
+
+
+@pytest.mark.parametrize("epi", ["none", "bias", "bias_gelu", "dgelu"])
+def test_gemm_fp8_random_with_epilogues(epi):
+    from uwudiff_amd import lib as L
+    from uwudiff_amd import ops
+
+    torch.manual_seed(3)
+    M, N, K = 1024, 768, 1152
+    a, b = torch.randn(M, K), torch.randn(N, K) * 0.05
+    bias = torch.randn(N)
+    aux = torch.randn(M, N).bfloat16()
+    sa = torch.tensor([448.0 / float(a.abs().max())], device="cuda")
+    sb = torch.tensor([448.0 / float(b.abs().max())], device="cuda")
+    a8, _ = ops.fp8_quantize(a.cuda(), sa, 0)
+    b8, _ = ops.fp8_quantize(b.cuda(), sb, 0)
+    ref = (deq(a8, 0) @ deq(b8, 0).t()) / (float(sa) * float(sb))  # what the kernel must compute (fp32)
+    if epi == "none":
+        c = ops.gemm_fp8(a8, b8, sa, sb)
+    elif epi == "bias":
+        c = ops.gemm_fp8(a8, b8, sa, sb, bias=bias.cuda(), epilogue=L.EPI_BIAS)
+        ref = ref + bias
+    elif epi == "bias_gelu":
+        c, c2 = ops.gemm_fp8(a8, b8, sa, sb, bias=bias.cuda(), epilogue=L.EPI_BIAS_GELU)
+        ref = ref + bias
+        torch.testing.assert_close(c2.float().cpu(), torch.nn.functional.gelu(ref, approximate="tanh"), rtol=2e-2, atol=2e-2)
+    else:
+        c = ops.gemm_fp8(a8, b8, sa, sb, aux=aux.cuda(), epilogue=L.EPI_DGELU)
+        u = aux.float().requires_grad_(True)
+        torch.nn.functional.gelu(u, approximate="tanh").sum().backward()
+        ref = ref * u.grad
+    torch.testing.assert_close(c.float().cpu(), ref, rtol=1e-2, atol=2e-2)  # bf16 output rounding
+    # and the quantisation itself stays within fp8's error of the unquantised product
+    full = a @ b.t()
+    assert ((deq(a8, 0) @ deq(b8, 0).t()) / (float(sa) * float(sb)) - full).norm() / full.norm() < 6e-2
+
+
+@pytest.mark.parametrize("fmt_a", [0, 1])
+def test_gemm_fp8_weight_gradient_accumulates(fmt_a):
+    """dW[N_out, K_in] += dY^T . X through the transposed fp8 copies (contraction over M tokens, split-K partial sums)."""
+    from uwudiff_amd import lib as L
+    from uwudiff_amd import ops
+
+    torch.manual_seed(5)
+    M, No, Ki = 4096, 1152, 384
+    dy, x = torch.randn(M, No) * 1e-3, torch.randn(M, Ki)
+    sa = torch.tensor([FMAX[fmt_a] / float(dy.abs().max())], device="cuda")
+    sb = torch.tensor([448.0 / float(x.abs().max())], device="cuda")
+    db = torch.zeros(No, device="cuda")
+    _, dyt = ops.fp8_quantize(dy.cuda(), sa, fmt_a, rowmajor=False, transposed=True, colsum=db)
+    _, xt = ops.fp8_quantize(x.cuda(), sb, 0, rowmajor=False, transposed=True)
+    dw0 = torch.randn(No, Ki)
+    dw = dw0.clone().cuda()
+    ops.gemm_fp8(dyt, xt, sa, sb, fmt_a=fmt_a, epilogue=L.EPI_ACCUM, out=dw)
+    ref = dw0 + (deq(dyt, fmt_a) @ deq(xt, 0).t()) / (float(sa) * float(sb))
+    torch.testing.assert_close(dw.cpu(), ref, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(db.cpu(), dy.sum(0), rtol=1e-4, atol=1e-6)
+    full = dw0 + dy.t() @ x
+    assert (dw.cpu() - full).norm() / full.norm() < 8e-2

@@ -1246,6 +1246,121 @@ __global__ void __launch_bounds__(256, 2) gemm_tr_kernel(const GemmArgs g) {
     }
 }
 
+// ---- fp8 (OCP e4m3 / e5m2) operands on the block-scaled MFMA: BASELINE config 5 ("fp8 MFMA GEMMs") -----------------------
+// v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (E8M0 = 127) runs at twice the bf16 rate (MI355X_MICROARCH.md,
+// Matrix cores) -- the non-scaled fp8 MFMAs only reach the bf16 rate.  ONE kernel shape serves forward, input gradient and
+// weight gradient because every operand is handed over contraction-contiguous ("NT"): the quantising kernels of
+// quant.hip write the transposed fp8 copies (W^T for dgrad, dY^T / X^T for wgrad) while they convert.
+//   C[M,N] = alpha * A[M,K] . B[N,K]^T,  alpha = 1 / (scale_a * scale_b)  (per-tensor quantisation scales, read from
+//   device memory so that delayed scaling needs no host round trip), fp32 accumulate, bf16 (or fp32 partial) out.
+// Structure = gemm_big_kernel: 256x256 tile, 8 waves (2 x 4 of 128 x 64), K-step = 128-byte rows = 128 fp8 = ONE MFMA
+// per 16x16 output fragment and step (the bf16 kernel: two MFMAs of K = 32), two LDS-DMA stages of 64 KB, same swizzled
+// image.  A lane's 32 operand bytes are 16-byte chunks fq and 4 + fq of the row -- a permutation of k applied to both
+// operands alike, chosen because those are exactly the two conflict-free reads of the bf16 kernel.
+// FA: element format of the A operand (0 = e4m3, 1 = e5m2: output gradients); B (weights / activations) is e4m3.
+// PART: split-K partial sums (fp32) into a dense scratch [split][M][N]; splitk_reduce_kernel adds them to C.
+struct f8_t { unsigned char v; };
+template <> struct GT<f8_t> { static constexpr int EPC = 16; static constexpr int BK = 128; };
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+template <typename TC, int EPI, int FA, bool PART>
+__global__ void __launch_bounds__(512, 2) gemm_f8_kernel(const GemmArgs g, const float* __restrict__ scale_a,
+                                                         const float* __restrict__ scale_b) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int STAGE = 4 * TILE_BYTES;  // A0 | A1 | W0 | W1
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int nblk = g.tiles_m * g.tiles_n;
+  int bid = blockIdx.x, zsl = 0;
+  if constexpr (PART) {  // K slices: XCD x takes slices x, x + 8, ... (all tiles of a slice share one L2, as gemm_tr_kernel)
+    const int xcd = bid & 7, loc = bid >> 3;
+    zsl = xcd + 8 * (loc / nblk);
+    bid = loc % nblk;
+    if (zsl >= g.wide) return;  // uniform per block
+  }
+  int tile = bid;
+  if constexpr (!PART) {  // XCD-aware tile order as in gemm_kernel
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int q = nblk >> 3, rm = nblk & 7;
+    tile = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + loc;
+  }
+  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  const int m0 = tm * 256, n0 = tn * 256;
+  int s_begin = 0, s_end = g.K >> 7;
+  if constexpr (PART) {
+    s_begin = zsl * g.k_tiles_per_split;
+    if (s_begin + g.k_tiles_per_split < s_end) s_end = s_begin + g.k_tiles_per_split;
+    if (s_end <= s_begin) return;  // uniform per block
+  }
+  const f8_t* A = static_cast<const f8_t*>(g.A);
+  const f8_t* B = static_cast<const f8_t*>(g.B);
+  const int half = tid >> 8, t256 = tid & 255;
+  auto issue = [&](int s) {
+    char* st = smem + (s & 1) * STAGE;
+    glds_tile<f8_t>(A, g.lda, m0 + 128 * half, s * 128, g.M, st + half * TILE_BYTES, t256);
+    glds_tile<f8_t>(B, g.ldb, n0 + 128 * half, s * 128, g.N, st + (2 + half) * TILE_BYTES, t256);
+  };
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto frag = [&](const char* base, int row) {
+    const uint4 lo = lds_read128_asm(base + swz(row, fq)), hi = lds_read128_asm(base + swz(row, 4 + fq));
+    return i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+  };
+
+  issue(s_begin);
+  for (int s = s_begin; s < s_end; ++s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stage s landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();                     // ... everybody's; everybody is done reading stage s - 1
+    if (s + 1 < s_end) issue(s + 1);
+    const char* la = smem + (s & 1) * STAGE + wm * TILE_BYTES;
+    const char* lb = smem + (s & 1) * STAGE + (2 + (wn >> 1)) * TILE_BYTES;
+    i32x8 bf[4], af[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bf[j] = frag(lb, (wn & 1) * 64 + 16 * j + fr);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = frag(la, 64 * h + 16 * i + fr);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)  // swapped operands (a lane ends up with 4 consecutive columns): MFMA-A = weight fragment
+          acc[4 * h + i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bf[j], af[i], acc[4 * h + i][j], 0, FA, 0,
+                                                                               0x7F7F7F7F, 0, 0x7F7F7F7F);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  const float alpha = 1.f / (scale_a[0] * scale_b[0]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = acc[i][j] * alpha;
+  if constexpr (PART) {
+    float* P = static_cast<float*>(g.C2) + (int64_t)zsl * g.M * g.N;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + wm * 128 + 16 * i + fr;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + 16 * j + 4 * fq;
+        if (m < g.M && n < g.N) store4(P + (int64_t)m * g.N + n, acc[i][j]);
+      }
+    }
+  } else {
+    EpiPre<bf16_t, 8, 4> pre;
+    epi_prefetch<bf16_t, 8, 4, EPI>(pre, g, m0 + wm * 128, n0 + wn * 64, fr, fq);
+    epilogue_tile<bf16_t, TC, 8, 4, EPI>(acc, pre, g, m0 + wm * 128, n0 + wn * 64, fr, fq,
+                                         reinterpret_cast<float*>(smem) + (wn >> 1) * 256, wm, wn & 1,
+                                         wm == 0 ? (tid & 127) : 128);
+  }
+}
+
 // ---- live profiler (prof.cpp): HIP event pairs around launches on the launch stream (bench.py `roofline`) -------
 // tag of a GEMM launch: forward / input gradient / weight gradient, the two GELU Linears apart
 static int gemm_tag(const GemmArgs& g, bool tb, bool acc) {
@@ -1566,7 +1681,106 @@ int dispatch_trans(const GemmArgs& g, int ta, int tb, bool acc, int split, hipSt
   return UWU_EINVAL;
 }
 
+template <int EPI, int FA>
+int launch_f8(GemmArgs g, const float* sa, const float* sb, hipStream_t st) {
+  auto kern = gemm_f8_kernel<bf16_t, EPI, FA, false>;
+  constexpr int LDS = 2 * 4 * TILE_BYTES;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_done = true;
+  }
+  g.tiles_m = (g.M + 255) / 256;
+  g.tiles_n = (g.N + 255) / 256;
+  UwuProfScope prof(st);
+  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(512), LDS, st, g, sa, sb);
+  prof.done(gemm_tag(g, false, false), 0, 2.0 * g.M * g.N * g.K, gemm_bytes(g, 1, 2));
+  UWU_LAUNCH_CHECK("gemm_f8");
+  return UWU_OK;
+}
+// number of K slices for an fp8 weight gradient: enough workgroups for ~2 rounds of the chip, >= 4 K-steps per slice
+int f8_split(int tiles, int steps) {
+  int split = (512 + tiles - 1) / tiles;
+  split = (split + 7) / 8 * 8;
+  while (split > 8 && split * 4 > steps) split -= 8;
+  if (split > steps) split = steps;
+  return split < 1 ? 1 : split;
+}
+template <int FA>
+int launch_f8_part(GemmArgs g, const float* sa, const float* sb, void* scratch, hipStream_t st) {
+  auto kern = gemm_f8_kernel<float, UWU_EPI_NONE, FA, true>;
+  constexpr int LDS = 2 * 4 * TILE_BYTES;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_done = true;
+  }
+  g.tiles_m = (g.M + 255) / 256;
+  g.tiles_n = (g.N + 255) / 256;
+  const int tiles = g.tiles_m * g.tiles_n, steps = g.K / 128;
+  int split = f8_split(tiles, steps);
+  g.k_tiles_per_split = (steps + split - 1) / split;
+  split = (steps + g.k_tiles_per_split - 1) / g.k_tiles_per_split;
+  g.wide = split;
+  g.C2 = scratch;
+  const int grid = 8 * tiles * ((split + 7) / 8);
+  UwuProfScope prof(st);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, st, g, sa, sb);
+  const int64_t quads = (int64_t)g.M * g.N / 4;
+  int rg = (int)((quads + 255) / 256);
+  if (rg > 4096) rg = 4096;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, st, static_cast<const float*>(scratch),
+                     static_cast<float*>(g.C), g.M, g.N, g.ldc, split);
+  prof.done(UWU_PROF_GEMM_WGRAD, 0, 2.0 * g.M * g.N * g.K, ((double)g.M * g.K + (double)g.N * g.K) + (double)g.M * g.N * 4);
+  UWU_LAUNCH_CHECK("gemm_f8(split-K)");
+  return UWU_OK;
+}
+
 }  // namespace
+
+extern "C" size_t uwu_gemm_fp8_scratch_bytes(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K < 128) return 0;
+  const int tiles = ((M + 255) / 256) * ((N + 255) / 256);
+  return (size_t)f8_split(tiles, K / 128) * M * N * sizeof(float);
+}
+
+extern "C" int uwu_gemm_fp8(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux, int M,
+                            int N, int K, int lda, int ldb, int ldc, int ldaux, int fmt_a, int epilogue,
+                            const float* scale_a, const float* scale_b, void* scratch, size_t scratch_bytes,
+                            void* stream) {
+  UWU_CHECK_ARG(A && B && C && scale_a && scale_b, "gemm_fp8: null operand");
+  UWU_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % 128 == 0, "gemm_fp8: K=%d must be a positive multiple of 128", K);
+  UWU_CHECK_ARG(fmt_a == UWU_FP8_E4M3 || fmt_a == UWU_FP8_E5M2, "gemm_fp8: bad operand format %d", fmt_a);
+  UWU_CHECK_ARG((((uintptr_t)A | (uintptr_t)B) & 15) == 0 && lda % 16 == 0 && ldb % 16 == 0 && lda >= K && ldb >= K,
+                "gemm_fp8: operands must be 16-byte aligned with leading dimensions that are multiples of 16");
+  GemmArgs g{};
+  g.A = A; g.B = B; g.C = C; g.C2 = C2; g.bias = bias; g.aux = aux;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux; g.epi = epilogue;
+  hipStream_t st = (hipStream_t)stream;
+  if (epilogue == UWU_EPI_ACCUM) {  // C fp32 += (weight gradient): split-K partial sums in `scratch`
+    UWU_CHECK_ARG(N % 4 == 0 && ldc % 4 == 0 && ldc >= N && ((uintptr_t)C & 15) == 0, "gemm_fp8: ACCUM needs 16-byte rows in C");
+    UWU_CHECK_ARG(scratch && ((uintptr_t)scratch & 15) == 0 && scratch_bytes >= uwu_gemm_fp8_scratch_bytes(M, N, K),
+                  "gemm_fp8: ACCUM needs uwu_gemm_fp8_scratch_bytes(M, N, K) of scratch");
+    return fmt_a == UWU_FP8_E5M2 ? launch_f8_part<1>(g, scale_a, scale_b, scratch, st)
+                                 : launch_f8_part<0>(g, scale_a, scale_b, scratch, st);
+  }
+  UWU_CHECK_ARG(N % 8 == 0 && ldc % 8 == 0 && ldc >= N && ((uintptr_t)C & 15) == 0, "gemm_fp8: N and ldc must be multiples of 8");
+  g.wide = 1;
+  if (epilogue == UWU_EPI_BIAS || epilogue == UWU_EPI_BIAS_GELU)
+    UWU_CHECK_ARG(bias && ((uintptr_t)bias & 15) == 0, "gemm_fp8: bias missing/misaligned");
+  if (epilogue == UWU_EPI_BIAS_GELU) UWU_CHECK_ARG(C2 && ((uintptr_t)C2 & 15) == 0, "gemm_fp8: C2 missing/misaligned");
+  if (epilogue == UWU_EPI_DGELU)
+    UWU_CHECK_ARG(aux && ldaux % 4 == 0 && ldaux >= N && ((uintptr_t)aux & 7) == 0, "gemm_fp8: aux missing/misaligned");
+#define F8_CASE(E)                                                                   \
+  case E:                                                                            \
+    return fmt_a == UWU_FP8_E5M2 ? launch_f8<E, 1>(g, scale_a, scale_b, st) : launch_f8<E, 0>(g, scale_a, scale_b, st);
+  switch (epilogue) {
+    F8_CASE(UWU_EPI_NONE) F8_CASE(UWU_EPI_BIAS) F8_CASE(UWU_EPI_BIAS_GELU) F8_CASE(UWU_EPI_DGELU)
+  }
+#undef F8_CASE
+  uwu_set_error("gemm_fp8: epilogue %d not available", epilogue);
+  return UWU_EINVAL;
+}
 
 extern "C" int uwu_gemm(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux, int M,
                         int N, int K, int lda, int ldb, int ldc, int ldaux, int transA, int transB, int dtype,

@@ -204,3 +204,52 @@ def gemm_wgrad(dy, x, dw, blocks=512, scratch=None, bias_grad=None):
 
 def gemm_wgrad_scratch(M, N, K, device="cuda"):
     return torch.empty(L.load().uwu_gemm_wgrad_scratch_bytes(M, N, K), dtype=torch.uint8, device=device)
+
+
+# ---------------------------------------------------------------------------------------------------- fp8 (config 5)
+FP8_E4M3, FP8_E5M2 = 0, 1
+FP8_MAX = {FP8_E4M3: 448.0, FP8_E5M2: 57344.0}
+
+
+def fp8_amax(x, amax=None):
+    if amax is None:
+        amax = torch.zeros(1, device=x.device, dtype=torch.float32)
+    L.call("uwu_fp8_amax", L.ptr(x), L.dt(x), x.numel(), L.ptr(amax), L.stream())
+    return amax
+
+
+def fp8_update_scales(amax, scale, fmt, margin=1.0):
+    """amax / scale: fp32 [n]; fmt: int32 [n] (FP8_E4M3 / FP8_E5M2).  scale = FMT_MAX / (amax * margin); amax <- 0."""
+    L.call("uwu_fp8_update_scales", L.ptr(amax), L.ptr(scale), L.ptr(fmt), amax.numel(), float(margin), L.stream())
+    return scale
+
+
+def fp8_quantize(x, scale, fmt=FP8_E4M3, *, rowmajor=True, transposed=False, amax=None, colsum=None):
+    """x [M,K] (bf16 / fp32) -> (uint8 [M,K] | None, uint8 [K,M] | None) in one pass over x."""
+    M, K = x.shape
+    out = torch.empty(M, K, device=x.device, dtype=torch.uint8) if rowmajor else None
+    out_t = torch.empty(K, M, device=x.device, dtype=torch.uint8) if transposed else None
+    L.call("uwu_fp8_quantize", L.ptr(x), L.dt(x), M, K, x.stride(0), L.ptr(scale), fmt, L.ptr(out), K, L.ptr(out_t), M,
+           L.ptr(amax), L.ptr(colsum), L.stream())
+    return out, out_t
+
+
+def gemm_fp8(a8, b8, scale_a, scale_b, *, fmt_a=FP8_E4M3, bias=None, aux=None, epilogue=L.EPI_NONE, out=None, out2=None):
+    """C[M,N] = (a8[M,K] . b8[N,K]^T) / (scale_a * scale_b): both operands uint8 fp8 bytes, contraction-contiguous."""
+    M, K = a8.shape
+    N, Kb = b8.shape
+    assert K == Kb and a8.dtype == torch.uint8 and b8.dtype == torch.uint8
+    scratch, sbytes = None, 0
+    if epilogue == L.EPI_ACCUM:
+        if out is None:
+            out = torch.zeros(M, N, device=a8.device, dtype=torch.float32)
+        sbytes = L.load().uwu_gemm_fp8_scratch_bytes(M, N, K)
+        scratch = torch.empty(sbytes, device=a8.device, dtype=torch.uint8)
+    elif out is None:
+        out = torch.empty(M, N, device=a8.device, dtype=torch.bfloat16)
+    if epilogue == L.EPI_BIAS_GELU and out2 is None:
+        out2 = torch.empty(M, N, device=a8.device, dtype=torch.bfloat16)
+    L.call("uwu_gemm_fp8", L.ptr(a8), L.ptr(b8), L.ptr(out), L.ptr(out2), L.ptr(bias), L.ptr(aux), M, N, K, a8.stride(0),
+           b8.stride(0), out.stride(0), aux.stride(0) if aux is not None else 0, fmt_a, epilogue, L.ptr(scale_a),
+           L.ptr(scale_b), L.ptr(scratch), sbytes, L.stream())
+    return (out, out2) if out2 is not None and epilogue == L.EPI_BIAS_GELU else out
