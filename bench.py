@@ -154,7 +154,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=DEFAULT_BATCH, help="per-GPU batch (weak scaling)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp8"],
+                    help="bf16 (headline); fp8 = BASELINE config 5 (DiT block Linears on e4m3 / e5m2 operands, block-scaled MFMA)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the per-GPU batch sweep (16 / 64 / 256) after the timed region")
     ap.add_argument("--clip", type=float, default=0.0)
@@ -318,7 +319,11 @@ def main():
                 if tjd.get("gemm_src_sha16") == src_sha16():
                     traffic = round(tjd["hbm_bytes_per_launch"])
                     traffic_src = "profiles/r02_pmc_gemm_traffic.json (separate --pmc passes over this command, same gemm.hip)"
-            roof = {"bound": "mfma", "kernel": "bf16 MFMA GEMM family (gemm_kernel / gemm_r3_kernel / gemm_big_kernel / gemm_wide_kernel / gemm_tr_kernel, v_mfma_f32_16x16x32_bf16; fwd+dgrad+wgrad launches)",
+            fam = ("fp8 block-scaled MFMA GEMM family (gemm_f8_kernel, v_mfma_scale_f32_16x16x128_f8f6f4: fwd + dgrad + split-K wgrad of the "
+                   "block Linears; the few Linears outside the blocks stay bf16)" if args.dtype == "fp8" else
+                   "bf16 MFMA GEMM family (gemm_kernel / gemm_r3_kernel / gemm_big_kernel / gemm_wide_kernel / gemm_tr_kernel, "
+                   "v_mfma_f32_16x16x32_bf16; fwd+dgrad+wgrad launches)")
+            roof = {"bound": "mfma", "kernel": fam,
                     "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": traffic, "traffic_source": traffic_src, "launches_per_step": n.value // n_prof,
                     "avg_launch_us": round(ms.value * 1e3 / n.value, 2),

@@ -339,6 +339,14 @@ typedef struct uwu_dit_desc {
                               stream once every parameter-gradient launch of block l has been issued, so a data-parallel
                               host can start reducing that block's slice of g32 while the backward continues
                               (blocks finish in the order L-1 .. 0; the non-block parameters finish last). */
+  /* fp8 Linears (BASELINE config 5): 0 = off; 1 = just-in-time per-tensor scaling (amax pass, then quantise); 2 = delayed
+   * scaling (quantise with the scale derived from the previous step's amax; call with 1 for the first step).  Needs
+   * dtype == UWU_BF16, D % 128 == 0.  Roles (12 per block, index 12*l + r): r 0-3 = inputs of qkv / proj / fc1 / fc2
+   * (e4m3), 4-7 = their output gradients (e5m2), 8-11 = their weights (e4m3). */
+  int32_t fp8;
+  float* f8_scale;      /* [12 L] per-tensor quantisation scales */
+  float* f8_amax;       /* [12 L] running max |x| of the current step */
+  const int32_t* f8_fmt; /* [12 L] UWU_FP8_E4M3 / UWU_FP8_E5M2 per role */
 } uwu_dit_desc;
 
 size_t uwu_dit_workspace_bytes(const uwu_dit_desc* d);

@@ -75,8 +75,8 @@ def test_gemm_fp8_exact_on_integers(fmt_a, M, N, K):
     b8, _ = ops.fp8_quantize(b.cuda(), sb, 0)
     c = ops.gemm_fp8(a8, b8, sa, sb, fmt_a=fmt_a)
     want = (a @ b.t())
-    assert want.abs().max() < 256  # exactly representable in bf16
-    assert torch.equal(c.float().cpu(), want)
+    # the fp32 accumulator holds these integers exactly; the only rounding is the final RNE to bf16
+    assert torch.equal(c.float().cpu(), want.bfloat16().float())
 
 
 @pytest.mark.parametrize("epi", ["none", "bias", "bias_gelu", "dgelu"])
@@ -136,3 +136,49 @@ def test_gemm_fp8_weight_gradient_accumulates(fmt_a):
     torch.testing.assert_close(db.cpu(), dy.sum(0), rtol=1e-4, atol=1e-6)
     full = dw0 + dy.t() @ x
     assert (dw.cpu() - full).norm() / full.norm() < 8e-2
+
+
+# ------------------------------------------------------------------------------------------------ whole model, fp8 Linears
+XL2_CUT = dict(depth=2, hidden=1152, heads=16, patch=2, sample_size=32, in_channels=4, out_channels=4, cond_dim=1280)
+
+
+def _rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("scaling", ["jit", "delayed"])
+def test_dit_xl2_width_fp8_close_to_oracle(scaling):
+    """DiT-XL/2 width (1152, 16 heads; depth cut to 2) with the block Linears on fp8 operands: forward and every parameter
+    gradient against the fp32 CPU oracle.  fp8 tolerances (e4m3 has 3 mantissa bits: ~3 % per element, averaged down by
+    the contractions); the bf16 path's are 3e-2 / 6e-2.  Delayed scaling: the second step uses the first step's amax."""
+    from oracle.dit import DiTOracle
+    from uwudiff_amd.dit import DiT, DiTConfig
+
+    torch.manual_seed(0)
+    ora = DiTOracle(**XL2_CUT)
+    with torch.no_grad():
+        for p in ora.parameters():
+            p.copy_(torch.randn_like(p) * (0.03 if p.dim() > 1 else 0.02))
+    model = DiT(DiTConfig(compute_dtype="fp8", fp8_scaling=scaling, **XL2_CUT), init="dit").cuda()
+    model.load_state_dict(ora.state_dict())
+    B = 8
+    g = torch.Generator().manual_seed(1)
+    for step in range(2 if scaling == "delayed" else 1):
+        x = torch.randn(B, 4, 32, 32, generator=g)
+        t = torch.randint(0, 1000, (B,), generator=g)
+        pooled = torch.randn(B, 1280, generator=g)
+        dout = torch.randn(B, 4, 32, 32, generator=g) / 1024
+        ora.zero_grad()
+        yo = ora(x, t, added_cond_kwargs={"text_embeds": pooled})[0]
+        yo.backward(dout)
+        model.flat.grad = torch.zeros_like(model.flat.data)
+        y = model(x.cuda(), t.cuda(), added_cond_kwargs={"text_embeds": pooled.cuda()})[0]
+        y.backward(dout.cuda())
+        torch.cuda.synchronize()
+    assert model._f8_mode == (2 if scaling == "delayed" else 1)
+    assert _rel(y, yo) < 6e-2, _rel(y, yo)
+    og = dict(ora.named_parameters())
+    bad = {n: _rel(model.grad_view(n), og[n].grad) for n, _ in model.named_tensors()
+           if _rel(model.grad_view(n), og[n].grad) >= 0.12}
+    assert not bad, bad

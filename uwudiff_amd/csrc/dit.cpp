@@ -34,6 +34,8 @@ struct Layout {
   // backward scratch
   size_t dx, dy, dh, dqkv, dao, du, delta, dotok, dmod, dsc, dc, dth, dtp;
   size_t wsc, wsc_bytes;  // split-K scratch of the weight-gradient GEMMs
+  // fp8 mode: quantised operand copies (reused by every Linear) and the per-layer fp8 weights (W and W^T)
+  size_t x8, x8t, dy8, dy8t, w8, w8_layer;
   size_t total;
 };
 
@@ -106,7 +108,20 @@ Layout make_layout(const uwu_dit_desc& d) {
                          uwu_gemm_wgrad_scratch_bytes((int)L.D3, d.D, (int)L.M),
                          uwu_gemm_wgrad_scratch_bytes(d.D, d.D, (int)L.M)})
     if (t > L.wsc_bytes) L.wsc_bytes = t;
+  if (d.fp8) {
+    for (const size_t t : {uwu_gemm_fp8_scratch_bytes((int)L.D4, d.D, (int)L.M), uwu_gemm_fp8_scratch_bytes(d.D, (int)L.D4, (int)L.M),
+                           uwu_gemm_fp8_scratch_bytes((int)L.D3, d.D, (int)L.M), uwu_gemm_fp8_scratch_bytes(d.D, d.D, (int)L.M)})
+      if (t > L.wsc_bytes) L.wsc_bytes = t;
+  }
   L.wsc = take(L.wsc_bytes);
+  if (d.fp8) {
+    L.x8 = take(L.M * L.D4);
+    L.x8t = take(L.M * L.D4);
+    L.dy8 = take(L.M * L.D4);
+    L.dy8t = take(L.M * L.D4);
+    L.w8_layer = al((size_t)24 * d.D * d.D);  // qkv | qkv^T | o | o^T | fc1 | fc1^T | fc2 | fc2^T
+    L.w8 = take((size_t)d.L * L.w8_layer);
+  }
   L.total = p;
   return L;
 }
@@ -127,6 +142,13 @@ int check_desc(const uwu_dit_desc* d) {
     return UWU_EINVAL;
   }
   if (!d->w || !d->w32 || !d->pos || !d->ws) { uwu_set_error("dit: null buffer"); return UWU_EINVAL; }
+  if (d->fp8) {
+    if (d->fp8 < 0 || d->fp8 > 2 || d->dtype != UWU_BF16 || d->D % 128 || d->mlp_ratio != 4 || ((int64_t)d->B * d->T) % 128 ||
+        !d->f8_scale || !d->f8_amax || !d->f8_fmt) {
+      uwu_set_error("dit: fp8 mode needs bf16 activations, D %% 128 == 0, B*T %% 128 == 0, mlp_ratio 4 and the scale / amax / fmt arrays");
+      return UWU_EINVAL;
+    }
+  }
   return UWU_OK;
 }
 
@@ -182,6 +204,59 @@ int lin_wgrad(const void* dY, const void* X, float* dW, int M, int N, int K, int
   if (split > ktiles) split = ktiles;
   if (split < 1) split = 1;
   return uwu_gemm(dY, X, dW, nullptr, nullptr, nullptr, N, K, M, N, K, K, 0, 1, 1, dt, UWU_F32, UWU_EPI_ACCUM, split, st);
+}
+
+
+// ---- fp8 Linears (BASELINE config 5) ----------------------------------------------------------------------------
+// Every operand of the block-scaled-MFMA GEMM is contraction-contiguous fp8, so each Linear quantises its input
+// (forward), and in the backward its output gradient (row-major for the input gradient, transposed for the weight
+// gradient; the bias gradient = its column sums comes out of the same pass) and the saved input (transposed).
+struct F8 {
+  int mode;  // 0 off, 1 just-in-time scaling, 2 delayed scaling
+  float* scale;
+  float* amax;
+  const int32_t* fmt;
+  char *x8, *x8t, *dy8, *dy8t, *wsc, *w8;
+  size_t wsc_bytes, w8_layer;
+  int D;
+  void* st;
+  int role(int l, int r) const { return 12 * l + r; }
+  // W (row-major [N,K]) and W^T ([K,N]) of Linear i (0 qkv, 1 proj, 2 fc1, 3 fc2) of block l
+  char* w(int l, int i, bool t) const {
+    static const int off[4] = {0, 6, 8, 16}, sz[4] = {3, 1, 4, 4};
+    return w8 + (size_t)l * w8_layer + ((size_t)off[i] + (t ? sz[i] : 0)) * D * D;
+  }
+  // quantise x [M,K] with the scale of `role`; jit: derive that scale from x first (amax pass + update)
+  int quant(const void* x, int dtype, int M, int K, int role, void* out, void* out_t, float* colsum, bool have_scale) const {
+    const int fm = role % 12 >= 4 && role % 12 < 8 ? UWU_FP8_E5M2 : UWU_FP8_E4M3;
+    if (!have_scale && mode == 1) {
+      RUN(uwu_fp8_amax(x, dtype, (int64_t)M * K, amax + role, st));
+      RUN(uwu_fp8_update_scales(amax + role, scale + role, fmt + role, 1, 1.f, st));
+    }
+    return uwu_fp8_quantize(x, dtype, M, K, K, scale + role, fm, out, K, out_t, M,
+                            (!have_scale && mode == 2) ? amax + role : nullptr, colsum, st);
+  }
+};
+
+// Y = X . W^T (+ epilogue) with fp8 operands: X is quantised here (role rx), the weight was quantised at the start of
+// the forward (role rw)
+int f8_fwd(const F8& f, const void* X, const void* W8, const float* bias, void* Y, void* Y2, int M, int N, int K, int rx,
+           int rw, int epi) {
+  RUN(f.quant(X, UWU_BF16, M, K, rx, f.x8, nullptr, nullptr, false));
+  return uwu_gemm_fp8(f.x8, W8, Y, Y2, bias, nullptr, M, N, K, K, K, N, 0, UWU_FP8_E4M3, epi, f.scale + rx, f.scale + rw,
+                      nullptr, 0, f.st);
+}
+// backward of Y[M,N] = X[M,K] . W[N,K]^T: dW[N,K] += dY^T X, db[N] += colsum(dY), dX[M,K] = dY . W (optionally x gelu'(aux),
+// colsum of dX into dcol).  X is the saved bf16 input (its forward scale is reused).
+int f8_bwd(const F8& f, const void* dY, const void* X, const void* W8t, float* dW, float* db, void* dX, const void* aux,
+           float* dcol, int M, int N, int K, int rdy, int rx, int rw) {
+  RUN(f.quant(dY, UWU_BF16, M, N, rdy, f.dy8, f.dy8t, db, false));
+  RUN(f.quant(X, UWU_BF16, M, K, rx, nullptr, f.x8t, nullptr, true));
+  RUN(uwu_gemm_fp8(f.dy8t, f.x8t, dW, nullptr, nullptr, nullptr, N, K, M, M, M, K, 0, UWU_FP8_E5M2, UWU_EPI_ACCUM,
+                   f.scale + rdy, f.scale + rx, f.wsc, f.wsc_bytes, f.st));
+  if (!dX) return UWU_OK;
+  return uwu_gemm_fp8(f.dy8, W8t, dX, dcol, nullptr, aux, M, K, N, N, N, K, K, UWU_FP8_E5M2, aux ? UWU_EPI_DGELU : UWU_EPI_NONE,
+                      f.scale + rdy, f.scale + rw, nullptr, 0, f.st);
 }
 
 struct Ptrs {
@@ -272,6 +347,22 @@ extern "C" int uwu_dit_forward(const uwu_dit_desc* dp, const float* noisy, const
               UWU_EPI_BIAS, st));
   const float* mod = P.at<float>(L.mod);
 
+  // ---- fp8 mode: this step's weights as fp8 (W for the forward, W^T for the input gradients), scaled per tensor
+  const F8 f8{d.fp8, d.f8_scale, d.f8_amax, d.f8_fmt, P.at<char>(L.x8), P.at<char>(L.x8t), P.at<char>(L.dy8),
+              P.at<char>(L.dy8t), P.at<char>(L.wsc), P.at<char>(L.w8), L.wsc_bytes, L.w8_layer, d.D, st};
+  if (d.fp8) {
+    if (d.fp8 == 2)  // delayed scaling: the scales of this step come from the amax values recorded during the last one
+      RUN(uwu_fp8_update_scales(d.f8_amax, d.f8_scale, d.f8_fmt, 12 * d.L, 1.f, st));
+    const F8 fw{1, d.f8_scale, d.f8_amax, d.f8_fmt, nullptr, nullptr, nullptr, nullptr, nullptr, f8.w8, 0, L.w8_layer, d.D, st};
+    for (int l = 0; l < d.L; ++l) {
+      const LayerW w = layer_weights(d, l);
+      const void* ws4[4] = {w.qkv_w, w.o_w, w.fc1_w, w.fc2_w};
+      const int rows[4] = {D3, D, D4, D}, cols[4] = {D, D, D, D4};
+      for (int i = 0; i < 4; ++i)  // weights always scale just in time (two small passes)
+        RUN(fw.quant(ws4[i], UWU_BF16, rows[i], cols[i], fw.role(l, 8 + i), fw.w(l, i, false), fw.w(l, i, true), nullptr, false));
+    }
+  }
+
   // ---- patch embedding (Conv2d k=p,s=p == patchify + GEMM) + fixed 2-D sin-cos positions
   RUN(uwu_patchify(noisy, P.at(L.tok), B, d.in_ch, d.img, d.img, d.patch, dt, st));
   RUN(lin_fwd(P.at(L.tok), wb + d.off_patch_w * es, w32 + d.off_patch_b, P.lay(0, L.o_x0), nullptr, M, D, (int)L.Kp, dt,
@@ -293,18 +384,25 @@ extern "C" int uwu_dit_forward(const uwu_dit_desc* dp, const float* noisy, const
                                   P.lay(l, L.o_h1), P.lay<float>(l, L.o_m1), P.lay<float>(l, L.o_r1), B, T, D,
                                   d.ln_eps, 0, dt, st));
     }
-    RUN(lin_fwd(P.lay(l, L.o_h1), w.qkv_w, w.qkv_b, P.lay(l, L.o_qkv), nullptr, M, D3, D, dt, dt, UWU_EPI_BIAS, st));
+    if (d.fp8) RUN(f8_fwd(f8, P.lay(l, L.o_h1), f8.w(l, 0, false), w.qkv_b, P.lay(l, L.o_qkv), nullptr, M, D3, D, f8.role(l, 0), f8.role(l, 8), UWU_EPI_BIAS));
+    else RUN(lin_fwd(P.lay(l, L.o_h1), w.qkv_w, w.qkv_b, P.lay(l, L.o_qkv), nullptr, M, D3, D, dt, dt, UWU_EPI_BIAS, st));
     char* qkv = P.lay<char>(l, L.o_qkv);
     RUN(uwu_attention_fwd(qkv, qkv + (size_t)D * es, qkv + (size_t)2 * D * es, P.lay(l, L.o_ao), P.lay<float>(l, L.o_lse),
                           B, T, T, d.H, D / d.H, D3, D3, D3, D, scale, dt, st));
-    RUN(lin_fwd(P.lay(l, L.o_ao), w.o_w, w.o_b, P.lay(l, L.o_y1), nullptr, M, D, D, dt, dt, UWU_EPI_BIAS, st));
+    if (d.fp8) RUN(f8_fwd(f8, P.lay(l, L.o_ao), f8.w(l, 1, false), w.o_b, P.lay(l, L.o_y1), nullptr, M, D, D, f8.role(l, 1), f8.role(l, 9), UWU_EPI_BIAS));
+    else RUN(lin_fwd(P.lay(l, L.o_ao), w.o_w, w.o_b, P.lay(l, L.o_y1), nullptr, M, D, D, dt, dt, UWU_EPI_BIAS, st));
     // x1 = x0 + gate_msa * y1 ; h2 = LN(x1)*(1+scale_mlp)+shift_mlp
     RUN(uwu_add_ln_modulate_fwd(x0, P.lay(l, L.o_y1), m + 2 * D, m + 3 * D, m + 4 * D, ML, P.lay(l, L.o_x1),
                                 P.lay(l, L.o_h2), P.lay<float>(l, L.o_m2), P.lay<float>(l, L.o_r2), B, T, D, d.ln_eps,
                                 0, dt, st));
-    RUN(lin_fwd(P.lay(l, L.o_h2), w.fc1_w, w.fc1_b, P.lay(l, L.o_u), P.lay(l, L.o_f), M, D4, D, dt, dt,
-                UWU_EPI_BIAS_GELU, st));
-    RUN(lin_fwd(P.lay(l, L.o_f), w.fc2_w, w.fc2_b, P.lay(l, L.o_y2), nullptr, M, D, D4, dt, dt, UWU_EPI_BIAS, st));
+    if (d.fp8) {
+      RUN(f8_fwd(f8, P.lay(l, L.o_h2), f8.w(l, 2, false), w.fc1_b, P.lay(l, L.o_u), P.lay(l, L.o_f), M, D4, D, f8.role(l, 2), f8.role(l, 10), UWU_EPI_BIAS_GELU));
+      RUN(f8_fwd(f8, P.lay(l, L.o_f), f8.w(l, 3, false), w.fc2_b, P.lay(l, L.o_y2), nullptr, M, D, D4, f8.role(l, 3), f8.role(l, 11), UWU_EPI_BIAS));
+    } else {
+      RUN(lin_fwd(P.lay(l, L.o_h2), w.fc1_w, w.fc1_b, P.lay(l, L.o_u), P.lay(l, L.o_f), M, D4, D, dt, dt,
+                  UWU_EPI_BIAS_GELU, st));
+      RUN(lin_fwd(P.lay(l, L.o_f), w.fc2_w, w.fc2_b, P.lay(l, L.o_y2), nullptr, M, D, D4, dt, dt, UWU_EPI_BIAS, st));
+    }
   }
   // ---- final adaLN + linear + unpatchify
   {
@@ -340,6 +438,8 @@ extern "C" int uwu_dit_backward(const uwu_dit_desc* dp, const float* dout, void*
     return UWU_ELAUNCH;
   }
   const float scale = 1.f / sqrtf((float)(D / d.H));
+  const F8 f8{d.fp8, d.f8_scale, d.f8_amax, d.f8_fmt, P.at<char>(L.x8), P.at<char>(L.x8t), P.at<char>(L.dy8),
+              P.at<char>(L.dy8t), P.at<char>(L.wsc), P.at<char>(L.w8), L.wsc_bytes, L.w8_layer, d.D, st};
 
   // ---- output head
   RUN(uwu_patchify(dout, P.at(L.dotok), B, d.out_ch, d.img, d.img, d.patch, dt, st));
@@ -362,31 +462,49 @@ extern "C" int uwu_dit_backward(const uwu_dit_desc* dp, const float* dout, void*
     const float* m = mod + (int64_t)l * 6 * D;
     float* dm = dmod + (int64_t)l * 6 * D;
     // ---- MLP branch: y2 = fc2(gelu(fc1(h2)))
+    if (d.fp8) {
+      // fc2: dW2, db2, du = (dy.W2) * gelu'(u) with colsum(du) = fc1.bias gradient;  fc1: dW1, dh = du.W1
+      RUN(f8_bwd(f8, P.at(L.dy), P.lay(l, L.o_f), f8.w(l, 3, true), g + w.off_fc2_w, g + w.off_fc2_b, P.at(L.du), P.lay(l, L.o_u),
+                 g + w.off_fc1_b, M, D, D4, f8.role(l, 7), f8.role(l, 3), f8.role(l, 11)));
+      RUN(f8_bwd(f8, P.at(L.du), P.lay(l, L.o_h2), f8.w(l, 2, true), g + w.off_fc1_w, nullptr, P.at(L.dh), nullptr, nullptr, M, D4, D,
+                 f8.role(l, 6), f8.role(l, 2), f8.role(l, 10)));
+    } else {
     RUN(lin_wgrad(P.at(L.dy), P.lay(l, L.o_f), g + w.off_fc2_w, M, D, D4, dt, st, P.at(L.wsc), L.wsc_bytes, g + w.off_fc2_b));
     // du = (dy.W2) * gelu'(u); the epilogue also accumulates colsum(du) = fc1.bias gradient
     RUN(lin_dgrad(P.at(L.dy), w.fc2_w, P.at(L.du), P.lay(l, L.o_u), M, D, D4, dt, st, g + w.off_fc1_b));
     RUN(lin_wgrad(P.at(L.du), P.lay(l, L.o_h2), g + w.off_fc1_w, M, D4, D, dt, st, P.at(L.wsc), L.wsc_bytes));
     RUN(lin_dgrad(P.at(L.du), w.fc1_w, P.at(L.dh), nullptr, M, D4, D, dt, st));
+    }
     // LN2 bwd (+ residual) and gate bwd of the attention branch
     RUN(uwu_add_ln_modulate_bwd(P.at(L.dh), P.lay(l, L.o_x1), P.lay<float>(l, L.o_m2), P.lay<float>(l, L.o_r2), m + 4 * D,
                                 P.at(L.dx), P.lay(l, L.o_y1), m + 2 * D, ML, P.at(L.dx), P.at(L.dy), dm + 3 * D,
                                 dm + 4 * D, dm + 2 * D, B, T, D, 0, dt, st));
     // ---- attention branch: y1 = proj(attn(qkv(h1)))
+    if (d.fp8) {
+      RUN(f8_bwd(f8, P.at(L.dy), P.lay(l, L.o_ao), f8.w(l, 1, true), g + w.off_o_w, g + w.off_o_b, P.at(L.dao), nullptr, nullptr, M, D, D,
+                 f8.role(l, 5), f8.role(l, 1), f8.role(l, 9)));
+    } else {
     RUN(lin_wgrad(P.at(L.dy), P.lay(l, L.o_ao), g + w.off_o_w, M, D, D, dt, st, P.at(L.wsc), L.wsc_bytes, g + w.off_o_b));
     RUN(lin_dgrad(P.at(L.dy), w.o_w, P.at(L.dao), nullptr, M, D, D, dt, st));
+    }
     char* qkv = P.lay<char>(l, L.o_qkv);
     char* dqkv = P.at<char>(L.dqkv);
     RUN(uwu_attention_bwd(qkv, qkv + (size_t)D * es, qkv + (size_t)2 * D * es, P.lay(l, L.o_ao), P.at(L.dao),
                           P.lay<float>(l, L.o_lse), P.at<float>(L.delta), dqkv, dqkv + (size_t)D * es,
                           dqkv + (size_t)2 * D * es, B, T, T, d.H, D / d.H, D3, D3, D3, D, scale, dt, st));
+    if (d.fp8) {  // (the input gradient follows the weight gradient inside f8_bwd; the block's event is recorded after both)
+      RUN(f8_bwd(f8, dqkv, P.lay(l, L.o_h1), f8.w(l, 0, true), g + w.off_qkv_w, g + w.off_qkv_b, P.at(L.dh), nullptr, nullptr, M, D3, D,
+                 f8.role(l, 4), f8.role(l, 0), f8.role(l, 8)));
+    } else {
     RUN(lin_wgrad(dqkv, P.lay(l, L.o_h1), g + w.off_qkv_w, M, D3, D, dt, st, P.at(L.wsc), L.wsc_bytes, g + w.off_qkv_b));
+    }
     // every parameter gradient of block l is now in flight on `st`
     if (d.layer_done && d.layer_done[l] &&
         hipEventRecord(static_cast<hipEvent_t>(d.layer_done[l]), static_cast<hipStream_t>(st)) != hipSuccess) {
       uwu_set_error("dit_backward: hipEventRecord(layer_done[%d]) failed", l);
       return UWU_ELAUNCH;
     }
-    RUN(lin_dgrad(dqkv, w.qkv_w, P.at(L.dh), nullptr, M, D3, D, dt, st));
+    if (!d.fp8) RUN(lin_dgrad(dqkv, w.qkv_w, P.at(L.dh), nullptr, M, D3, D, dt, st));
     // LN1 bwd (+ residual) and gate bwd of the previous layer's MLP branch
     if (l > 0) {
       const float* mp = mod + (int64_t)(l - 1) * 6 * D;

@@ -46,7 +46,8 @@ class DiTConfig:
     cond_dim: int = 0          # pooled-text width (SDXL: 1280); 0 = unconditional
     freq_dim: int = 256
     ln_eps: float = 1e-6
-    compute_dtype: str = "bf16"  # "bf16" | "fp32"
+    compute_dtype: str = "bf16"  # "bf16" | "fp32" | "fp8" (bf16 activations, fp8 e4m3 / e5m2 operands of the block Linears)
+    fp8_scaling: str = "delayed"  # "delayed" (amax of the previous step; the first step scales just in time) | "jit"
 
 
 def _pad64(n):
@@ -124,6 +125,8 @@ class DiT(nn.Module):
         self._grad_groups = None
         self._fwd_gen = 0
         self._desc = None
+        self._f8 = None        # (scale, amax, fmt) device tensors of the fp8 mode, 12 roles per block
+        self._f8_steps = 0     # forward passes taken in fp8 mode (the first one always scales just in time)
         self.config = type("cfg", (), dict(in_channels=c.in_channels, sample_size=c.sample_size))()
         self.reset_parameters(init)
 
@@ -189,7 +192,7 @@ class DiT(nn.Module):
     @torch.no_grad()
     def refresh_shadow(self):
         """bf16 copy of the flat parameters for the MFMA operands (kept fresh by the fused AdamW afterwards)."""
-        if self.cfg.compute_dtype != "bf16" or not self.flat.is_cuda:
+        if self.cfg.compute_dtype not in ("bf16", "fp8") or not self.flat.is_cuda:
             return
         if self.shadow.numel() != self.n_flat or self.shadow.device != self.flat.device:
             self.shadow = torch.empty(self.n_flat, device=self.flat.device, dtype=torch.bfloat16)
@@ -210,7 +213,7 @@ class DiT(nn.Module):
         c = self.cfg
         if not self.flat.is_cuda:
             raise L.UwuError("DiT runs on the HIP device only; move the module with .cuda() (no CPU fallback)")
-        bf = c.compute_dtype == "bf16"
+        bf = c.compute_dtype in ("bf16", "fp8")
         if bf and self.shadow.numel() != self.n_flat:
             self.refresh_shadow()
         d = L.DitDesc()
@@ -233,7 +236,16 @@ class DiT(nn.Module):
         if c.depth > 1:
             assert r["blocks.1.qkv.weight"][0] - d.off_layer0 == d.layer_stride
         d.pos = self.pos.data_ptr()
-        key = (B, d.dtype, self.flat.device)
+        d.fp8 = 0
+        if c.compute_dtype == "fp8":
+            if self._f8 is None or self._f8[0].device != self.flat.device:
+                n = 12 * c.depth
+                fmt = torch.tensor(([0] * 4 + [1] * 4 + [0] * 4) * c.depth, dtype=torch.int32, device=self.flat.device)
+                self._f8 = (torch.zeros(n, device=self.flat.device), torch.zeros(n, device=self.flat.device), fmt)
+                self._f8_steps = 0
+            d.fp8 = 1 if (c.fp8_scaling == "jit" or self._f8_steps == 0) else 2
+            d.f8_scale, d.f8_amax, d.f8_fmt = (t.data_ptr() for t in self._f8)
+        key = (B, d.dtype, d.fp8 != 0, self.flat.device)
         if self._ws_key != key:
             d.ws, d.ws_bytes = None, 0
             need = L.load().uwu_dit_workspace_bytes(ctypes.byref(d))
@@ -284,12 +296,16 @@ class DiT(nn.Module):
                           dtype=torch.float32)
         L.call("uwu_dit_forward", ctypes.byref(d), L.ptr(noisy), L.ptr(t), L.ptr(cond), L.ptr(out), L.stream())
         self._fwd_gen += 1
+        self._f8_mode = d.fp8
+        if d.fp8:
+            self._f8_steps += 1
         return out
 
     def _run_backward(self, dout, cond):
         if self.flat.grad is None:
             self.flat.grad = torch.zeros_like(self.flat.data)
         d = self._descriptor(dout.shape[0])
+        d.fp8 = getattr(self, "_f8_mode", 0)  # the backward uses the scaling policy its forward used
         L.call("uwu_dit_backward", ctypes.byref(d), L.ptr(dout), L.stream())
         if self._grad_hook is not None:
             self._grad_hook(self.flat.grad, self._grad_groups)
