@@ -30,6 +30,7 @@ struct Layout {
   size_t layer0, layer_stride;
   // per-layer sub-offsets
   size_t o_x0, o_m1, o_r1, o_h1, o_qkv, o_lse, o_ao, o_y1, o_x1, o_m2, o_r2, o_h2, o_u, o_f, o_y2;
+  size_t o_h1t, o_aot, o_h2t, o_ft;  // fp8 mode: transposed fp8 copies of the Linear inputs (operands of the weight gradients)
   size_t xF, mF, rF, hF, otok;
   // backward scratch
   size_t dx, dy, dh, dqkv, dao, du, delta, dotok, dmod, dsc, dc, dth, dtp;
@@ -81,6 +82,12 @@ Layout make_layout(const uwu_dit_desc& d) {
   L.o_u = sub(L.M * L.D4 * L.es);
   L.o_f = sub(L.M * L.D4 * L.es);
   L.o_y2 = sub(L.M * L.D * L.es);
+  if (d.fp8) {
+    L.o_h1t = sub(L.M * L.D);
+    L.o_aot = sub(L.M * L.D);
+    L.o_h2t = sub(L.M * L.D);
+    L.o_ft = sub(L.M * L.D4);
+  }
   L.layer_stride = q;
   L.layer0 = p;
   p += (size_t)d.L * L.layer_stride;
@@ -116,7 +123,7 @@ Layout make_layout(const uwu_dit_desc& d) {
   L.wsc = take(L.wsc_bytes);
   if (d.fp8) {
     L.x8 = take(L.M * L.D4);
-    L.x8t = take(L.M * L.D4);
+    L.x8t = 0;
     L.dy8 = take(L.M * L.D4);
     L.dy8t = take(L.M * L.D4);
     L.w8_layer = al((size_t)24 * d.D * d.D);  // qkv | qkv^T | o | o^T | fc1 | fc1^T | fc2 | fc2^T
@@ -240,19 +247,19 @@ struct F8 {
 
 // Y = X . W^T (+ epilogue) with fp8 operands: X is quantised here (role rx), the weight was quantised at the start of
 // the forward (role rw)
-int f8_fwd(const F8& f, const void* X, const void* W8, const float* bias, void* Y, void* Y2, int M, int N, int K, int rx,
-           int rw, int epi) {
-  RUN(f.quant(X, UWU_BF16, M, K, rx, f.x8, nullptr, nullptr, false));
+int f8_fwd(const F8& f, const void* X, void* Xt_save, const void* W8, const float* bias, void* Y, void* Y2, int M, int N, int K,
+           int rx, int rw, int epi) {
+  // one pass over X: the row-major copy for this GEMM and the transposed copy the weight gradient will contract over
+  RUN(f.quant(X, UWU_BF16, M, K, rx, f.x8, Xt_save, nullptr, false));
   return uwu_gemm_fp8(f.x8, W8, Y, Y2, bias, nullptr, M, N, K, K, K, N, 0, UWU_FP8_E4M3, epi, f.scale + rx, f.scale + rw,
                       nullptr, 0, f.st);
 }
 // backward of Y[M,N] = X[M,K] . W[N,K]^T: dW[N,K] += dY^T X, db[N] += colsum(dY), dX[M,K] = dY . W (optionally x gelu'(aux),
-// colsum of dX into dcol).  X is the saved bf16 input (its forward scale is reused).
-int f8_bwd(const F8& f, const void* dY, const void* X, const void* W8t, float* dW, float* db, void* dX, const void* aux,
+// colsum of dX into dcol).  X8t = the transposed fp8 copy of the input saved by the forward (scale of role rx).
+int f8_bwd(const F8& f, const void* dY, const void* X8t, const void* W8t, float* dW, float* db, void* dX, const void* aux,
            float* dcol, int M, int N, int K, int rdy, int rx, int rw) {
   RUN(f.quant(dY, UWU_BF16, M, N, rdy, f.dy8, f.dy8t, db, false));
-  RUN(f.quant(X, UWU_BF16, M, K, rx, nullptr, f.x8t, nullptr, true));
-  RUN(uwu_gemm_fp8(f.dy8t, f.x8t, dW, nullptr, nullptr, nullptr, N, K, M, M, M, K, 0, UWU_FP8_E5M2, UWU_EPI_ACCUM,
+  RUN(uwu_gemm_fp8(f.dy8t, X8t, dW, nullptr, nullptr, nullptr, N, K, M, M, M, K, 0, UWU_FP8_E5M2, UWU_EPI_ACCUM,
                    f.scale + rdy, f.scale + rx, f.wsc, f.wsc_bytes, f.st));
   if (!dX) return UWU_OK;
   return uwu_gemm_fp8(f.dy8, W8t, dX, dcol, nullptr, aux, M, K, N, N, N, K, K, UWU_FP8_E5M2, aux ? UWU_EPI_DGELU : UWU_EPI_NONE,
@@ -348,7 +355,7 @@ extern "C" int uwu_dit_forward(const uwu_dit_desc* dp, const float* noisy, const
   const float* mod = P.at<float>(L.mod);
 
   // ---- fp8 mode: this step's weights as fp8 (W for the forward, W^T for the input gradients), scaled per tensor
-  const F8 f8{d.fp8, d.f8_scale, d.f8_amax, d.f8_fmt, P.at<char>(L.x8), P.at<char>(L.x8t), P.at<char>(L.dy8),
+  const F8 f8{d.fp8, d.f8_scale, d.f8_amax, d.f8_fmt, P.at<char>(L.x8), nullptr, P.at<char>(L.dy8),
               P.at<char>(L.dy8t), P.at<char>(L.wsc), P.at<char>(L.w8), L.wsc_bytes, L.w8_layer, d.D, st};
   if (d.fp8) {
     if (d.fp8 == 2)  // delayed scaling: the scales of this step come from the amax values recorded during the last one
@@ -384,20 +391,20 @@ extern "C" int uwu_dit_forward(const uwu_dit_desc* dp, const float* noisy, const
                                   P.lay(l, L.o_h1), P.lay<float>(l, L.o_m1), P.lay<float>(l, L.o_r1), B, T, D,
                                   d.ln_eps, 0, dt, st));
     }
-    if (d.fp8) RUN(f8_fwd(f8, P.lay(l, L.o_h1), f8.w(l, 0, false), w.qkv_b, P.lay(l, L.o_qkv), nullptr, M, D3, D, f8.role(l, 0), f8.role(l, 8), UWU_EPI_BIAS));
+    if (d.fp8) RUN(f8_fwd(f8, P.lay(l, L.o_h1), P.lay(l, L.o_h1t), f8.w(l, 0, false), w.qkv_b, P.lay(l, L.o_qkv), nullptr, M, D3, D, f8.role(l, 0), f8.role(l, 8), UWU_EPI_BIAS));
     else RUN(lin_fwd(P.lay(l, L.o_h1), w.qkv_w, w.qkv_b, P.lay(l, L.o_qkv), nullptr, M, D3, D, dt, dt, UWU_EPI_BIAS, st));
     char* qkv = P.lay<char>(l, L.o_qkv);
     RUN(uwu_attention_fwd(qkv, qkv + (size_t)D * es, qkv + (size_t)2 * D * es, P.lay(l, L.o_ao), P.lay<float>(l, L.o_lse),
                           B, T, T, d.H, D / d.H, D3, D3, D3, D, scale, dt, st));
-    if (d.fp8) RUN(f8_fwd(f8, P.lay(l, L.o_ao), f8.w(l, 1, false), w.o_b, P.lay(l, L.o_y1), nullptr, M, D, D, f8.role(l, 1), f8.role(l, 9), UWU_EPI_BIAS));
+    if (d.fp8) RUN(f8_fwd(f8, P.lay(l, L.o_ao), P.lay(l, L.o_aot), f8.w(l, 1, false), w.o_b, P.lay(l, L.o_y1), nullptr, M, D, D, f8.role(l, 1), f8.role(l, 9), UWU_EPI_BIAS));
     else RUN(lin_fwd(P.lay(l, L.o_ao), w.o_w, w.o_b, P.lay(l, L.o_y1), nullptr, M, D, D, dt, dt, UWU_EPI_BIAS, st));
     // x1 = x0 + gate_msa * y1 ; h2 = LN(x1)*(1+scale_mlp)+shift_mlp
     RUN(uwu_add_ln_modulate_fwd(x0, P.lay(l, L.o_y1), m + 2 * D, m + 3 * D, m + 4 * D, ML, P.lay(l, L.o_x1),
                                 P.lay(l, L.o_h2), P.lay<float>(l, L.o_m2), P.lay<float>(l, L.o_r2), B, T, D, d.ln_eps,
                                 0, dt, st));
     if (d.fp8) {
-      RUN(f8_fwd(f8, P.lay(l, L.o_h2), f8.w(l, 2, false), w.fc1_b, P.lay(l, L.o_u), P.lay(l, L.o_f), M, D4, D, f8.role(l, 2), f8.role(l, 10), UWU_EPI_BIAS_GELU));
-      RUN(f8_fwd(f8, P.lay(l, L.o_f), f8.w(l, 3, false), w.fc2_b, P.lay(l, L.o_y2), nullptr, M, D, D4, f8.role(l, 3), f8.role(l, 11), UWU_EPI_BIAS));
+      RUN(f8_fwd(f8, P.lay(l, L.o_h2), P.lay(l, L.o_h2t), f8.w(l, 2, false), w.fc1_b, P.lay(l, L.o_u), P.lay(l, L.o_f), M, D4, D, f8.role(l, 2), f8.role(l, 10), UWU_EPI_BIAS_GELU));
+      RUN(f8_fwd(f8, P.lay(l, L.o_f), P.lay(l, L.o_ft), f8.w(l, 3, false), w.fc2_b, P.lay(l, L.o_y2), nullptr, M, D, D4, f8.role(l, 3), f8.role(l, 11), UWU_EPI_BIAS));
     } else {
       RUN(lin_fwd(P.lay(l, L.o_h2), w.fc1_w, w.fc1_b, P.lay(l, L.o_u), P.lay(l, L.o_f), M, D4, D, dt, dt,
                   UWU_EPI_BIAS_GELU, st));
@@ -438,7 +445,7 @@ extern "C" int uwu_dit_backward(const uwu_dit_desc* dp, const float* dout, void*
     return UWU_ELAUNCH;
   }
   const float scale = 1.f / sqrtf((float)(D / d.H));
-  const F8 f8{d.fp8, d.f8_scale, d.f8_amax, d.f8_fmt, P.at<char>(L.x8), P.at<char>(L.x8t), P.at<char>(L.dy8),
+  const F8 f8{d.fp8, d.f8_scale, d.f8_amax, d.f8_fmt, P.at<char>(L.x8), nullptr, P.at<char>(L.dy8),
               P.at<char>(L.dy8t), P.at<char>(L.wsc), P.at<char>(L.w8), L.wsc_bytes, L.w8_layer, d.D, st};
 
   // ---- output head
@@ -464,9 +471,9 @@ extern "C" int uwu_dit_backward(const uwu_dit_desc* dp, const float* dout, void*
     // ---- MLP branch: y2 = fc2(gelu(fc1(h2)))
     if (d.fp8) {
       // fc2: dW2, db2, du = (dy.W2) * gelu'(u) with colsum(du) = fc1.bias gradient;  fc1: dW1, dh = du.W1
-      RUN(f8_bwd(f8, P.at(L.dy), P.lay(l, L.o_f), f8.w(l, 3, true), g + w.off_fc2_w, g + w.off_fc2_b, P.at(L.du), P.lay(l, L.o_u),
+      RUN(f8_bwd(f8, P.at(L.dy), P.lay(l, L.o_ft), f8.w(l, 3, true), g + w.off_fc2_w, g + w.off_fc2_b, P.at(L.du), P.lay(l, L.o_u),
                  g + w.off_fc1_b, M, D, D4, f8.role(l, 7), f8.role(l, 3), f8.role(l, 11)));
-      RUN(f8_bwd(f8, P.at(L.du), P.lay(l, L.o_h2), f8.w(l, 2, true), g + w.off_fc1_w, nullptr, P.at(L.dh), nullptr, nullptr, M, D4, D,
+      RUN(f8_bwd(f8, P.at(L.du), P.lay(l, L.o_h2t), f8.w(l, 2, true), g + w.off_fc1_w, nullptr, P.at(L.dh), nullptr, nullptr, M, D4, D,
                  f8.role(l, 6), f8.role(l, 2), f8.role(l, 10)));
     } else {
     RUN(lin_wgrad(P.at(L.dy), P.lay(l, L.o_f), g + w.off_fc2_w, M, D, D4, dt, st, P.at(L.wsc), L.wsc_bytes, g + w.off_fc2_b));
@@ -481,7 +488,7 @@ extern "C" int uwu_dit_backward(const uwu_dit_desc* dp, const float* dout, void*
                                 dm + 4 * D, dm + 2 * D, B, T, D, 0, dt, st));
     // ---- attention branch: y1 = proj(attn(qkv(h1)))
     if (d.fp8) {
-      RUN(f8_bwd(f8, P.at(L.dy), P.lay(l, L.o_ao), f8.w(l, 1, true), g + w.off_o_w, g + w.off_o_b, P.at(L.dao), nullptr, nullptr, M, D, D,
+      RUN(f8_bwd(f8, P.at(L.dy), P.lay(l, L.o_aot), f8.w(l, 1, true), g + w.off_o_w, g + w.off_o_b, P.at(L.dao), nullptr, nullptr, M, D, D,
                  f8.role(l, 5), f8.role(l, 1), f8.role(l, 9)));
     } else {
     RUN(lin_wgrad(P.at(L.dy), P.lay(l, L.o_ao), g + w.off_o_w, M, D, D, dt, st, P.at(L.wsc), L.wsc_bytes, g + w.off_o_b));
@@ -493,7 +500,7 @@ extern "C" int uwu_dit_backward(const uwu_dit_desc* dp, const float* dout, void*
                           P.lay<float>(l, L.o_lse), P.at<float>(L.delta), dqkv, dqkv + (size_t)D * es,
                           dqkv + (size_t)2 * D * es, B, T, T, d.H, D / d.H, D3, D3, D3, D, scale, dt, st));
     if (d.fp8) {  // (the input gradient follows the weight gradient inside f8_bwd; the block's event is recorded after both)
-      RUN(f8_bwd(f8, dqkv, P.lay(l, L.o_h1), f8.w(l, 0, true), g + w.off_qkv_w, g + w.off_qkv_b, P.at(L.dh), nullptr, nullptr, M, D3, D,
+      RUN(f8_bwd(f8, dqkv, P.lay(l, L.o_h1t), f8.w(l, 0, true), g + w.off_qkv_w, g + w.off_qkv_b, P.at(L.dh), nullptr, nullptr, M, D3, D,
                  f8.role(l, 4), f8.role(l, 0), f8.role(l, 8)));
     } else {
     RUN(lin_wgrad(dqkv, P.lay(l, L.o_h1), g + w.off_qkv_w, M, D3, D, dt, st, P.at(L.wsc), L.wsc_bytes, g + w.off_qkv_b));

@@ -11,8 +11,8 @@
 //   out_t [K, M]  (the operand of a contraction over M: X^T / dY^T of the weight gradient, W^T of the input gradient),
 //   colsum[K] +=  column sums of x in fp32 (the bias gradient of the Linear whose dY is being quantised),
 //   amax          max |x| (atomic max on the float bits).
-// HBM-bound: 64 x 64 tiles, 16-byte loads, the transposed copy goes through an LDS byte image so that its stores are
-// 16 bytes per lane along M.
+// HBM-bound: 128 x 64 tiles, 16-byte loads; the transposed copy is packed four rows to a dword in registers (v_perm_b32),
+// crosses an LDS dword image and leaves as 32 contiguous bytes per lane along M (whole 128-byte lines per k row).
 #include "common.h"
 
 namespace {
@@ -28,8 +28,12 @@ __device__ __forceinline__ unsigned cvt2(float a, float b) {  // two fp8 bytes i
   else return (unsigned)__builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false) & 0xFFFFu;
 }
 
-__device__ __forceinline__ void atomic_max_pos(float* dst, float v) {  // v >= 0: the bit pattern is monotone
-  atomicMax(reinterpret_cast<unsigned*>(dst), __float_as_uint(v));
+// v >= 0: the bit pattern is monotone.  Atomics on ONE address serialise at ~12 ns each (MI355X_MICROARCH.md "fanin"):
+// with one per workgroup a 27 000-workgroup launch spent 0.33 ms on them alone, so a workgroup first looks at the value
+// (an L2-coherent load; a stale smaller value only costs an unnecessary atomic) and almost all of them skip it.
+__device__ __forceinline__ void atomic_max_pos(float* dst, float v) {
+  const unsigned cur = __hip_atomic_load(reinterpret_cast<unsigned*>(dst), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (__float_as_uint(v) > cur) atomicMax(reinterpret_cast<unsigned*>(dst), __float_as_uint(v));
 }
 
 template <typename T>
@@ -61,27 +65,29 @@ __global__ void update_scales_kernel(float* __restrict__ amax, float* __restrict
   amax[i] = 0.f;
 }
 
-// one 64 (m) x 64 (k) tile per workgroup
+// one 128 (m) x 64 (k) tile per workgroup; thread = (8-element k chunk c, group of 4 rows rg)
 template <typename T, int FMT>
 __global__ void __launch_bounds__(256) quantize_kernel(const T* __restrict__ x, int M, int K, int ldx,
                                                        const float* __restrict__ scale, unsigned char* __restrict__ out,
                                                        int ldo, unsigned char* __restrict__ out_t, int ldt,
                                                        float* __restrict__ amax, float* __restrict__ colsum) {
-  __shared__ __attribute__((aligned(16))) unsigned char img[64][64 + 16];  // [k][m], padded rows (80 B)
+  constexpr int P = 33;                 // dword pitch of the transposed image (odd: the b32 accesses spread over the banks)
+  __shared__ unsigned img[64 * P];      // [k][m / 4]: one dword = 4 consecutive rows of one column
   __shared__ float cs[4][64];
   __shared__ float red[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_k = (K + 63) / 64;
   const int tm = blockIdx.x / tiles_k, tk = blockIdx.x - tm * tiles_k;
-  const int m0 = tm * 64, k0 = tk * 64;
+  const int m0 = tm * 128, k0 = tk * 64;
   const float s = scale[0];
-  const int c = tid & 7, rr = tid >> 3;  // 8 lanes x 8 elements per row, 32 rows per pass
+  const int c = tid & 7, rg = tid >> 3;
   const int k = k0 + 8 * c;
   float mx = 0.f;
   f32x8 csum = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint2 pk[4];
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const int ml = rr + 32 * p, m = m0 + ml;
+  for (int r = 0; r < 4; ++r) {
+    const int m = m0 + 4 * rg + r;
     f32x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
     if (m < M && k + 8 <= K) v = load8(x + (int64_t)m * ldx + k);
     else if (m < M)
@@ -92,23 +98,29 @@ __global__ void __launch_bounds__(256) quantize_kernel(const T* __restrict__ x, 
     csum = csum + v;
     const unsigned b01 = cvt2<FMT>(v[0] * s, v[1] * s), b23 = cvt2<FMT>(v[2] * s, v[3] * s);
     const unsigned b45 = cvt2<FMT>(v[4] * s, v[5] * s), b67 = cvt2<FMT>(v[6] * s, v[7] * s);
-    const uint2 packed = {b01 | (b23 << 16), b45 | (b67 << 16)};
+    pk[r] = uint2{b01 | (b23 << 16), b45 | (b67 << 16)};
     if (out && m < M) {
-      if (k + 8 <= K) *reinterpret_cast<uint2*>(out + (int64_t)m * ldo + k) = packed;
+      if (k + 8 <= K) *reinterpret_cast<uint2*>(out + (int64_t)m * ldo + k) = pk[r];
       else
         for (int e = 0; e < 8; ++e)
-          if (k + e < K) out[(int64_t)m * ldo + k + e] = (unsigned char)((e < 4 ? packed.x : packed.y) >> (8 * (e & 3)));
+          if (k + e < K) out[(int64_t)m * ldo + k + e] = (unsigned char)((e < 4 ? pk[r].x : pk[r].y) >> (8 * (e & 3)));
     }
-    if (out_t) {
+  }
+  if (out_t) {  // byte e of the four rows -> one dword of column 8c + e (v_perm_b32: two selects per dword)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) img[8 * c + e][ml] = (unsigned char)((e < 4 ? packed.x : packed.y) >> (8 * (e & 3)));
+    for (int e = 0; e < 8; ++e) {
+      const unsigned w0 = e < 4 ? pk[0].x : pk[0].y, w1 = e < 4 ? pk[1].x : pk[1].y;
+      const unsigned w2 = e < 4 ? pk[2].x : pk[2].y, w3 = e < 4 ? pk[3].x : pk[3].y;
+      const unsigned sel = 0x0c0c0400u + (unsigned)(e & 3) * 0x0101u;                // {0, 0, w1[e], w0[e]}
+      const unsigned lo = __builtin_amdgcn_perm(w1, w0, sel), hi = __builtin_amdgcn_perm(w3, w2, sel);
+      img[(8 * c + e) * P + rg] = lo | (hi << 16);
     }
   }
   if (amax) {
     mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
   }
-  if (colsum) {  // lanes with equal c (stride 8) hold the same columns: fold the 8 row slots of the wave, then the waves
+  if (colsum) {  // lanes with equal c (stride 8) hold the same columns: fold the 8 row groups of the wave, then the waves
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float t = csum[e];
@@ -121,14 +133,20 @@ __global__ void __launch_bounds__(256) quantize_kernel(const T* __restrict__ x, 
   __syncthreads();
   if (amax && tid == 0) atomic_max_pos(amax, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
   if (colsum && tid < 64 && k0 + tid < K) atomicAdd(colsum + k0 + tid, cs[0][tid] + cs[1][tid] + cs[2][tid] + cs[3][tid]);
-  if (out_t) {  // thread -> (k row, 16-byte segment of m)
+  if (out_t) {  // thread -> (k row, 32-row segment of m): 32 contiguous bytes, four lanes cover a 128-byte line
     const int kr = tid >> 2, seg = tid & 3;
-    const int kk = k0 + kr, mm = m0 + 16 * seg;
+    const int kk = k0 + kr, mm = m0 + 32 * seg;
     if (kk < K && mm < M) {
-      const uint4 v = *reinterpret_cast<const uint4*>(&img[kr][16 * seg]);
-      if (mm + 16 <= M) *reinterpret_cast<uint4*>(out_t + (int64_t)kk * ldt + mm) = v;
-      else
-        for (int e = 0; e < 16 && mm + e < M; ++e) out_t[(int64_t)kk * ldt + mm + e] = img[kr][16 * seg + e];
+      unsigned w[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) w[i] = img[kr * P + 8 * seg + i];
+      unsigned char* dst = out_t + (int64_t)kk * ldt + mm;
+      if (mm + 32 <= M) {
+        *reinterpret_cast<uint4*>(dst) = uint4{w[0], w[1], w[2], w[3]};
+        *reinterpret_cast<uint4*>(dst + 16) = uint4{w[4], w[5], w[6], w[7]};
+      } else {
+        for (int e = 0; e < 32 && mm + e < M; ++e) dst[e] = (unsigned char)(w[e >> 2] >> (8 * (e & 3)));
+      }
     }
   }
 }
@@ -164,7 +182,7 @@ extern "C" int uwu_fp8_quantize(const void* x, int dtype, int M, int K, int ldx,
   UWU_CHECK_ARG(((uintptr_t)x & 15) == 0 && ldx % 8 == 0, "fp8_quantize: x must be 16-byte aligned, ldx % 8 == 0");
   UWU_CHECK_ARG(!out || (ldo >= K && ldo % 8 == 0 && ((uintptr_t)out & 7) == 0), "fp8_quantize: out / ldo misaligned");
   UWU_CHECK_ARG(!out_t || (ldt >= M && ldt % 16 == 0 && ((uintptr_t)out_t & 15) == 0), "fp8_quantize: out_t / ldt misaligned");
-  const int64_t tiles = (int64_t)((M + 63) / 64) * ((K + 63) / 64);
+  const int64_t tiles = (int64_t)((M + 127) / 128) * ((K + 63) / 64);
   UWU_CHECK_ARG(tiles < (1ll << 31), "fp8_quantize: too many tiles");
   hipStream_t st = (hipStream_t)stream;
   UwuProfScope prof(stream);
