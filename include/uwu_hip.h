@@ -165,6 +165,21 @@ int uwu_gemm_fp8(const void* A, const void* B, void* C, void* C2, const float* b
                  int K, int lda, int ldb, int ldc, int ldaux, int fmt_a, int epilogue, const float* scale_a,
                  const float* scale_b, void* scratch, size_t scratch_bytes, void* stream);
 
+/* 3x3 convolution, padding 1, stride 1 or 2, channels-last bf16, as an implicit GEMM: the MFMA ring kernels gather
+ * their activation operand pixel by pixel (per-lane LDS-DMA source addresses, a zero page for the padding) so no
+ * im2col matrix exists in HBM (reference: the resblock / down / up-sample Conv2d of diffusers' UNet2DConditionModel,
+ * src/duwu/modules/unet_patch.py:13-57).  x [B,H,W,C], w [Cout][3][3][C] (the layout of this build's flat parameter
+ * blob), y / dy [B,Ho,Wo,Cout].  uwu_conv3x3_implicit_ok tells whether a shape is covered (bf16, C and Cout multiples
+ * of 32, B*Ho*Wo a multiple of 32); other shapes use uwu_im2col3x3 + uwu_gemm.  wgrad accumulates into fp32 dw / db. */
+int uwu_conv3x3_implicit_ok(int B, int H, int W, int C, int Cout, int stride, int dtype);
+int uwu_conv3x3_fwd(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int C, int Cout,
+                    int stride, int dtype, void* stream);
+int uwu_conv3x3_dgrad(const void* dy, const void* w, void* dx, int B, int H, int W, int C, int Cout, int stride, int dtype,
+                      void* stream);
+size_t uwu_conv3x3_wgrad_scratch_bytes(int C, int Cout, int64_t Mo);
+int uwu_conv3x3_wgrad(const void* dy, const void* x, float* dw, float* db, int B, int H, int W, int C, int Cout, int stride,
+                      int dtype, void* scratch, size_t scratch_bytes, void* stream);
+
 /* Per-tensor fp8 quantisation (quant.hip).  amax: device float, max |x| is folded in with an atomic max (caller zeroes
  * it, or uwu_fp8_update_scales does).  update_scales: scale[i] = FMT_MAX(fmt[i]) / (amax[i] * margin) where amax[i] > 0
  * (otherwise the previous scale, or 1), then amax[i] = 0 -- the "delayed scaling" step between two training steps, or

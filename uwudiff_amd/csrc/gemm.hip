@@ -24,6 +24,12 @@
 
 #include "common.h"
 
+#define RETURN_IF(expr)            \
+  do {                             \
+    const int rc_ = (expr);        \
+    if (rc_ != UWU_OK) return rc_; \
+  } while (0)
+
 namespace {
 
 constexpr int BM = 128, BN = 128;
@@ -175,7 +181,18 @@ struct GemmArgs {
   const float* bias;
   const void* aux;
   int M, N, K, lda, ldb, ldc, ldaux, epi, tiles_m, tiles_n, k_tiles_per_split, wide;
+  // implicit-GEMM 3x3 convolution (padding 1): geometry of the gathered operand (CONV template parameters)
+  int cH, cW, cC, cHo, cWo, cS;  // input H x W x C (channels-last), output Ho x Wo, stride
+  const void* zero;              // >= 16 zero bytes in device memory: the source of padded / out-of-range pixels
 };
+
+// n / d and n % d for 0 <= n < 2^24 (exact in fp32): one multiply + a correction instead of an integer division
+__device__ __forceinline__ void divmod24(int n, int d, float rcp, int& q, int& r) {
+  q = (int)((float)n * rcp);
+  r = n - q * d;
+  if (r < 0) { r += d; --q; }
+  if (r >= d) { r -= d; ++q; }
+}
 
 // Epilogue of one wave tile of FI x FJ 16x16 accumulators in the swapped-operand orientation (each lane owns 4
 // consecutive columns of one row): bias / GELU / dGELU(+column sums) math and 8- or 16-byte stores.
@@ -551,7 +568,14 @@ __device__ __forceinline__ unsigned tr_lane_base(int lane, int t, int xb8) {
   return (unsigned)(256 * krow + 16 * ((xb8 + (tp >> 1)) ^ f) + 8 * (tp & 1));
 }
 
-template <typename TC, int EPI, bool TB, int FI>
+// CONV (implicit-GEMM 3x3 convolution, channels-last, padding 1; no im2col matrix in HBM): the A rows are gathered --
+// LDS-DMA takes a per-lane source address, so a K-step of a tap reads the tile's pixels shifted by that tap and the
+// zero page where the tap falls outside the image.  K runs channel-chunk-major, tap-minor: the nine taps of a 32-channel
+// chunk re-read the same few KB of activations (L1 / L2 hits) before the next chunk is touched.
+//   CONV = 1 forward:  Y[(b,oy,ox), co] = sum_{tap,c} X[b, oy s + ky - 1, ox s + kx - 1, c] W[co][tap][c]   (TB = 0)
+//   CONV = 2 dgrad:    dX[(b,iy,ix), c] = sum_{tap,co} dY[b, (iy + 1 - ky) / s, (ix + 1 - kx) / s, co] W[co][tap][c]
+//                      (TB = 1: for a fixed tap the weight is a [co][c] matrix with row stride 9 C)
+template <typename TC, int EPI, bool TB, int FI, int CONV = 0>
 __global__ void __launch_bounds__(256, 2) gemm_r3_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef bf16_t T;
@@ -579,11 +603,26 @@ __global__ void __launch_bounds__(256, 2) gemm_r3_kernel(const GemmArgs g) {
   const int csrc = ((lane & 3) ^ r_gsw(prow)) & 3;  // logical chunk that must land at position lane & 3
   const T* pa[QA];
   const T* pb[2];
+  int cy[QA], cx[QA];  // CONV: row -> (image base folded into pa, y, x) of the output (1) / input (2) pixel
+  const T* const zsrc = static_cast<const T*>(g.zero) + 8 * 0;
 #pragma unroll
   for (int q = 0; q < QA; ++q) {
     int row = m0 + 16 * (wave + 4 * q) + prow;
-    if (row >= g.M) row = g.M - 1;
-    pa[q] = static_cast<const T*>(g.A) + (int64_t)row * g.lda + 8 * csrc;
+    if constexpr (CONV == 0) {
+      if (row >= g.M) row = g.M - 1;
+      pa[q] = static_cast<const T*>(g.A) + (int64_t)row * g.lda + 8 * csrc;
+    } else {
+      // rows of this GEMM = pixels of the (CONV 1: output, CONV 2: input) image; the gathered tensor is the other one
+      const int RH = CONV == 1 ? g.cHo : g.cH, RW = CONV == 1 ? g.cWo : g.cW;  // row image
+      const int GH = CONV == 1 ? g.cH : g.cHo, GW = CONV == 1 ? g.cW : g.cWo;  // gathered image
+      int b, rem, y, x;
+      divmod24(row < g.M ? row : 0, RH * RW, 1.f / (float)(RH * RW), b, rem);
+      divmod24(rem, RW, 1.f / (float)RW, y, x);
+      if (row >= g.M) y = -100000;  // every tap out of range -> zero rows
+      cy[q] = y;
+      cx[q] = x;
+      pa[q] = static_cast<const T*>(g.A) + (int64_t)b * GH * GW * g.lda + 8 * csrc;
+    }
   }
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
@@ -602,13 +641,47 @@ __global__ void __launch_bounds__(256, 2) gemm_r3_kernel(const GemmArgs g) {
   const int64_t bstep = TB ? (int64_t)32 * g.ldb : 32;
   auto issue = [&](int s) {
     char* st = smem + (s % NST) * STAGE + wave * 1024;
+    int64_t boff = s * bstep;
+    if constexpr (CONV != 0) {
+      const int ch = s / 9, tap = s - 9 * ch, ky = tap / 3, kx = tap - 3 * ky;  // wave-uniform
+      // weight: [co][tap][c].  forward (TB = 0): row co, columns tap C + 32 ch;  dgrad (TB = 1): rows 32 ch .. of the
+      // [co][c] matrix of this tap (row stride ldb = 9 C)
+      boff = TB ? (int64_t)32 * ch * g.ldb + tap * g.cC : (int64_t)tap * g.cC + 32 * ch;
 #pragma unroll
-    for (int q = 0; q < QA; ++q)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[q] + s * 32),
-                                       (__attribute__((address_space(3))) void*)(st + q * 4096), 16, 0, 0);
+      for (int q = 0; q < QA; ++q) {
+        int gy, gx;
+        bool ok;
+        if constexpr (CONV == 1) {
+          gy = cy[q] * g.cS + ky - 1;
+          gx = cx[q] * g.cS + kx - 1;
+          ok = gy >= 0 && gy < g.cH && gx >= 0 && gx < g.cW;
+        } else {
+          const int ty = cy[q] + 1 - ky, tx = cx[q] + 1 - kx;
+          ok = ty >= 0 && tx >= 0;
+          if (g.cS == 2) {
+            ok = ok && !((ty | tx) & 1);
+            gy = ty >> 1;
+            gx = tx >> 1;
+          } else {
+            gy = ty;
+            gx = tx;
+          }
+          ok = ok && gy < g.cHo && gx < g.cWo;
+        }
+        const int GW = CONV == 1 ? g.cW : g.cWo;
+        const T* src = ok ? pa[q] + (int64_t)(gy * GW + gx) * g.lda + 32 * ch : zsrc;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(st + q * 4096), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < QA; ++q)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[q] + s * 32),
+                                         (__attribute__((address_space(3))) void*)(st + q * 4096), 16, 0, 0);
+    }
 #pragma unroll
     for (int q = 0; q < 2; ++q)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb[q] + s * bstep),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb[q] + boff),
                                        (__attribute__((address_space(3))) void*)(st + A_BYTES + q * 4096), 16, 0, 0);
   };
 
@@ -1067,7 +1140,10 @@ constexpr int T_PS = 6;                // DMA instructions per wave per K-step (
 // PART: the split-K partial goes to a dense scratch [split][M][N] with plain 16-byte stores (swapped MFMA operands:
 // a lane owns 4 consecutive columns) and splitk_reduce_kernel adds the slices to C -- global fp32 atomics move only
 // ~1.3 TB/s chip-wide, and with ~500 workgroups x 128 KB of accumulators they cost as much as the whole K loop.
-template <int FI, int FJ, bool PART>
+// CONVW (weight gradient of the implicit-GEMM 3x3 convolution): dW[co][(tap, c)] += sum_m dY[m][co] X[pixel(m) + tap][c].
+// The B rows (K index m = output pixel) are gathered per lane: column x -> (tap, c) is fixed per lane, the pixel of
+// row m is recomputed every K-step (two divmod24), padded positions read the zero page.
+template <int FI, int FJ, bool PART, bool CONVW = false>
 __global__ void __launch_bounds__(256, 2) gemm_tr_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef bf16_t T;
@@ -1099,6 +1175,7 @@ __global__ void __launch_bounds__(256, 2) gemm_tr_kernel(const GemmArgs g) {
   const int dsw = ((drow & 3) << 2) | (wave & 3);  // f(row) of the destination row: (P & 7) & 3 == wave & 3
   const int dchunk = (lane & 15) ^ dsw;            // logical chunk that must land at position lane & 15
   const T* src[T_PS];
+  int ctap[T_PS];  // CONVW: ky * 4 + kx of this lane's column in piece q
 #pragma unroll
   for (int q = 0; q < T_PS; ++q) {
     const int P = wave + 4 * q, S = P >> 3, lp = P & 7;
@@ -1107,15 +1184,36 @@ __global__ void __launch_bounds__(256, 2) gemm_tr_kernel(const GemmArgs g) {
     const int X = isA ? g.M : g.N;
     if (x > X - 8) x = X - 8;  // columns past the operand: clamped (their products are never accumulated)
     const T* base = static_cast<const T*>(isA ? g.A : g.B);
-    src[q] = base + (int64_t)(s_begin * 32 + 4 * lp + drow) * (isA ? g.lda : g.ldb) + x;
+    ctap[q] = 0;
+    if (CONVW && !isA) {
+      int tap, c;
+      divmod24(x, g.cC, 1.f / (float)g.cC, tap, c);
+      const int ky = tap / 3;
+      ctap[q] = ky * 4 + (tap - 3 * ky);
+      src[q] = base + c;
+    } else {
+      src[q] = base + (int64_t)(s_begin * 32 + 4 * lp + drow) * (isA ? g.lda : g.ldb) + x;
+    }
   }
   const int64_t stepA = (int64_t)32 * g.lda, stepB = (int64_t)32 * g.ldb;
+  const float rcp_img = CONVW ? 1.f / (float)(g.cHo * g.cWo) : 0.f, rcp_w = CONVW ? 1.f / (float)g.cWo : 0.f;
   auto issue = [&](int s) {  // s = step index relative to s_begin
     char* st = smem + (s % T_NST) * T_STAGE;
 #pragma unroll
     for (int q = 0; q < T_PS; ++q) {
       const int P = wave + 4 * q, S = P >> 3, lp = P & 7;
-      const T* p = src[q] + s * (S < NA ? stepA : stepB);
+      const T* p;
+      if (CONVW && S >= NA) {
+        const int m = (s_begin + s) * 32 + 4 * lp + drow;  // output pixel (b, oy, ox); g.K = B Ho Wo is a multiple of 32
+        int b, rem, oy, ox;
+        divmod24(m, g.cHo * g.cWo, rcp_img, b, rem);
+        divmod24(rem, g.cWo, rcp_w, oy, ox);
+        const int gy = oy * g.cS + (ctap[q] >> 2) - 1, gx = ox * g.cS + (ctap[q] & 3) - 1;
+        const bool ok = gy >= 0 && gy < g.cH && gx >= 0 && gx < g.cW;
+        p = ok ? src[q] + ((int64_t)(b * g.cH + gy) * g.cW + gx) * g.cC : static_cast<const T*>(g.zero);
+      } else {
+        p = src[q] + s * (S < NA ? stepA : stepB);
+      }
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
                                        (__attribute__((address_space(3))) void*)(st + S * T_SUB + lp * 1024), 16, 0, 0);
     }
@@ -1394,9 +1492,9 @@ int launch(const GemmArgs& g, int split, hipStream_t st) {
   return UWU_OK;
 }
 
-template <typename TC, int EPI, bool TB, int FI>
+template <typename TC, int EPI, bool TB, int FI, int CONV = 0>
 int launch_r3(GemmArgs g, hipStream_t st) {
-  auto kern = gemm_r3_kernel<TC, EPI, TB, FI>;
+  auto kern = gemm_r3_kernel<TC, EPI, TB, FI, CONV>;
   constexpr int LDS = (FI == 8 ? 3 : 4) * (32 * FI * R_ROWB + R_BSUB);
   static bool attr_done = false;
   if (!attr_done) {
@@ -1407,7 +1505,8 @@ int launch_r3(GemmArgs g, hipStream_t st) {
   g.tiles_n = (g.N + 127) / 128;
   UwuProfScope prof(st);
   hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(256), LDS, st, g);
-  prof.done(gemm_tag(g, TB, false), 0, 2.0 * g.M * g.N * g.K, gemm_bytes(g, 2, sizeof(TC)));
+  if (CONV) prof.done(UWU_PROF_CONV, 0, 2.0 * g.M * g.N * g.K, ((double)g.M * g.K / 9 + (double)g.N * g.K + (double)g.M * g.N) * 2);
+  else prof.done(gemm_tag(g, TB, false), 0, 2.0 * g.M * g.N * g.K, gemm_bytes(g, 2, sizeof(TC)));
   UWU_LAUNCH_CHECK("gemm_r3");
   return UWU_OK;
 }
@@ -1513,13 +1612,13 @@ int tr_split(int tiles, int steps) {
   return split < 1 ? 1 : split;
 }
 
-template <int FI, int FJ>
+template <int FI, int FJ, bool CONVW = false>
 int launch_tr(GemmArgs g, void* scratch, size_t scratch_bytes, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tr_kernel<FI, FJ, false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tr_kernel<FI, FJ, false, CONVW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, T_NST * T_STAGE);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tr_kernel<FI, FJ, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tr_kernel<FI, FJ, true, CONVW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, T_NST * T_STAGE);
     attr_done = true;
   }
@@ -1537,16 +1636,16 @@ int launch_tr(GemmArgs g, void* scratch, size_t scratch_bytes, hipStream_t st) {
   UwuProfScope prof(st);
   if (part) {
     g.C2 = scratch;
-    hipLaunchKernelGGL((gemm_tr_kernel<FI, FJ, true>), dim3(grid), dim3(256), T_NST * T_STAGE, st, g);
+    hipLaunchKernelGGL((gemm_tr_kernel<FI, FJ, true, CONVW>), dim3(grid), dim3(256), T_NST * T_STAGE, st, g);
     const int64_t quads = (int64_t)g.M * g.N / 4;
     int rg = (int)((quads + 255) / 256);
     if (rg > 4096) rg = 4096;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, st, static_cast<const float*>(scratch),
                        static_cast<float*>(g.C), g.M, g.N, g.ldc, split);
   } else {
-    hipLaunchKernelGGL((gemm_tr_kernel<FI, FJ, false>), dim3(grid), dim3(256), T_NST * T_STAGE, st, g);
+    hipLaunchKernelGGL((gemm_tr_kernel<FI, FJ, false, CONVW>), dim3(grid), dim3(256), T_NST * T_STAGE, st, g);
   }
-  prof.done(UWU_PROF_GEMM_WGRAD, 0, 2.0 * g.M * g.N * g.K, ((double)g.M * g.K + (double)g.N * g.K) * 2 + (double)g.M * g.N * 4);
+  prof.done(CONVW ? UWU_PROF_CONV : UWU_PROF_GEMM_WGRAD, 0, 2.0 * g.M * g.N * g.K, ((double)g.M * g.K + (double)g.N * g.K) * 2 + (double)g.M * g.N * 4);
   UWU_LAUNCH_CHECK("gemm_tr");
   return UWU_OK;
 }
@@ -1737,6 +1836,85 @@ int launch_f8_part(GemmArgs g, const float* sa, const float* sb, void* scratch, 
 }
 
 }  // namespace
+
+// ---- implicit-GEMM 3x3 convolution (padding 1, stride 1 / 2, channels-last bf16): no im2col matrix ------------------------
+__device__ uint4 g_conv_zero[4];  // zero page for padded pixels (zero-initialised device memory)
+
+static const void* conv_zero_page() {
+  static void* p = nullptr;
+  if (!p && hipGetSymbolAddress(&p, HIP_SYMBOL(g_conv_zero)) != hipSuccess) p = nullptr;
+  return p;
+}
+
+extern "C" int uwu_conv3x3_implicit_ok(int B, int H, int W, int C, int Cout, int stride, int dtype) {
+  if (dtype != UWU_BF16 || C % 32 || Cout % 32 || C < 32 || Cout < 32 || (stride != 1 && stride != 2)) return 0;
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const int64_t Mi = (int64_t)B * H * W, Mo = (int64_t)B * Ho * Wo;
+  if (Mi >= (1 << 24) || Mo >= (1 << 24) || Mo % 32 || 9 * (int64_t)C >= (1 << 24)) return 0;
+  return 1;
+}
+
+static int conv_args(GemmArgs& g, int B, int H, int W, int C, int stride) {
+  g.cH = H; g.cW = W; g.cC = C; g.cS = stride;
+  g.cHo = (H - 1) / stride + 1;
+  g.cWo = (W - 1) / stride + 1;
+  g.zero = conv_zero_page();
+  if (!g.zero) { uwu_set_error("conv3x3: zero page unavailable"); return UWU_ELAUNCH; }
+  return UWU_OK;
+}
+
+// y[(b,oy,ox), co] = sum x[b, oy s + ky - 1, ox s + kx - 1, c] w[co][ky][kx][c] + bias[co]
+extern "C" int uwu_conv3x3_fwd(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int C, int Cout,
+                               int stride, int dtype, void* stream) {
+  UWU_CHECK_ARG(x && w && y && B > 0 && H > 0 && W > 0, "conv3x3_fwd: bad argument");
+  UWU_CHECK_ARG(uwu_conv3x3_implicit_ok(B, H, W, C, Cout, stride, dtype), "conv3x3_fwd: shape not covered by the implicit-GEMM kernel (C=%d Cout=%d)", C, Cout);
+  UWU_CHECK_ARG((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0), "conv3x3_fwd: misaligned tensor");
+  GemmArgs g{};
+  RETURN_IF(conv_args(g, B, H, W, C, stride));
+  g.A = x; g.B = w; g.C = y; g.bias = bias;
+  g.M = B * g.cHo * g.cWo; g.N = Cout; g.K = 9 * C; g.lda = C; g.ldb = 9 * C; g.ldc = Cout;
+  g.epi = bias ? UWU_EPI_BIAS : UWU_EPI_NONE;
+  g.wide = (Cout % 8 == 0) ? 1 : 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (bias) return launch_r3<bf16_t, UWU_EPI_BIAS, false, 8, 1>(g, st);
+  return launch_r3<bf16_t, UWU_EPI_NONE, false, 8, 1>(g, st);
+}
+
+// dx[(b,iy,ix), c] = sum dy[b, (iy + 1 - ky) / s, (ix + 1 - kx) / s, co] w[co][ky][kx][c]   (positions that divide evenly)
+extern "C" int uwu_conv3x3_dgrad(const void* dy, const void* w, void* dx, int B, int H, int W, int C, int Cout, int stride,
+                                 int dtype, void* stream) {
+  UWU_CHECK_ARG(dy && w && dx && B > 0 && H > 0 && W > 0, "conv3x3_dgrad: bad argument");
+  UWU_CHECK_ARG(uwu_conv3x3_implicit_ok(B, H, W, C, Cout, stride, dtype), "conv3x3_dgrad: shape not covered by the implicit-GEMM kernel");
+  UWU_CHECK_ARG((((uintptr_t)dy | (uintptr_t)w | (uintptr_t)dx) & 15) == 0, "conv3x3_dgrad: misaligned tensor");
+  GemmArgs g{};
+  RETURN_IF(conv_args(g, B, H, W, C, stride));
+  g.A = dy; g.B = w; g.C = dx;
+  g.M = B * H * W; g.N = C; g.K = 9 * Cout; g.lda = Cout; g.ldb = 9 * C; g.ldc = C;
+  g.epi = UWU_EPI_NONE;
+  g.wide = (C % 8 == 0) ? 1 : 0;
+  return launch_r3<bf16_t, UWU_EPI_NONE, true, 8, 2>(g, (hipStream_t)stream);
+}
+
+extern "C" size_t uwu_conv3x3_wgrad_scratch_bytes(int C, int Cout, int64_t Mo) {
+  return uwu_gemm_wgrad_scratch_bytes(Cout, 9 * C, (int)Mo);
+}
+// dw[co][ky][kx][c] += sum dy[(b,oy,ox), co] x[b, oy s + ky - 1, ox s + kx - 1, c];  db[co] += sum dy
+extern "C" int uwu_conv3x3_wgrad(const void* dy, const void* x, float* dw, float* db, int B, int H, int W, int C, int Cout,
+                                 int stride, int dtype, void* scratch, size_t scratch_bytes, void* stream) {
+  UWU_CHECK_ARG(dy && x && dw && B > 0 && H > 0 && W > 0, "conv3x3_wgrad: bad argument");
+  UWU_CHECK_ARG(uwu_conv3x3_implicit_ok(B, H, W, C, Cout, stride, dtype), "conv3x3_wgrad: shape not covered by the implicit-GEMM kernel");
+  UWU_CHECK_ARG((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dw) & 15) == 0, "conv3x3_wgrad: misaligned tensor");
+  GemmArgs g{};
+  RETURN_IF(conv_args(g, B, H, W, C, stride));
+  g.A = dy; g.B = x; g.C = dw; g.bias = db;
+  g.M = Cout; g.N = 9 * C; g.K = B * g.cHo * g.cWo; g.lda = Cout; g.ldb = C; g.ldc = 9 * C;
+  g.epi = UWU_EPI_ACCUM;
+  auto padded = [](int v, int b) { return (double)(((v + b - 1) / b) * b) / v; };
+  const bool tall = padded(g.M, 256) * padded(g.N, 128) <= padded(g.M, 128) * padded(g.N, 256);
+  hipStream_t st = (hipStream_t)stream;
+  if (tall) return launch_tr<8, 4, true>(g, scratch, scratch_bytes, st);
+  return launch_tr<4, 8, true>(g, scratch, scratch_bytes, st);
+}
 
 extern "C" size_t uwu_gemm_fp8_scratch_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K < 128) return 0;

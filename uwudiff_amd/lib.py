@@ -88,6 +88,11 @@ _SIGS = {
     "uwu_groupnorm_bwd": (c_int, [P] * 10 + [c_int] * 6 + [P]),
     "uwu_im2col3x3": (c_int, [P, P] + [c_int] * 6 + [P]),
     "uwu_col2im3x3": (c_int, [P, P] + [c_int] * 6 + [P]),
+    "uwu_conv3x3_implicit_ok": (c_int, [c_int] * 7),
+    "uwu_conv3x3_fwd": (c_int, [P, P, P, P] + [c_int] * 7 + [P]),
+    "uwu_conv3x3_dgrad": (c_int, [P, P, P] + [c_int] * 7 + [P]),
+    "uwu_conv3x3_wgrad_scratch_bytes": (ctypes.c_size_t, [c_int, c_int, c_int64]),
+    "uwu_conv3x3_wgrad": (c_int, [P, P, P, P] + [c_int] * 7 + [P, ctypes.c_size_t, P]),
     "uwu_geglu_fwd": (c_int, [P, P, c_int64, c_int, c_int, P]),
     "uwu_geglu_bwd": (c_int, [P, P, P, c_int64, c_int, c_int, P]),
     "uwu_upsample2x": (c_int, [P, P] + [c_int] * 6 + [P]),

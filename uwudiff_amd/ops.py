@@ -116,6 +116,39 @@ def col2im3x3(dcol, B, H, W, C, stride=1):
     return dx
 
 
+def conv3x3_implicit_ok(x, B, H, W, C, Cout, stride):
+    return x.is_cuda and bool(L.load().uwu_conv3x3_implicit_ok(B, H, W, C, Cout, stride, L.dt(x)))
+
+
+def conv3x3_fwd(x, w, bias, B, H, W, C, Cout, stride=1):
+    """Implicit-GEMM 3x3 convolution: x [B*H*W, C] channels-last, w [Cout, 9*C] (tap-major), -> [B*Ho*Wo, Cout]."""
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = torch.empty(B * Ho * Wo, Cout, device=x.device, dtype=x.dtype)
+    L.call("uwu_conv3x3_fwd", L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(y), B, H, W, C, Cout, stride, L.dt(x), L.stream())
+    return y
+
+
+def conv3x3_dgrad(dy, w, B, H, W, C, Cout, stride=1):
+    dx = torch.empty(B * H * W, C, device=dy.device, dtype=dy.dtype)
+    L.call("uwu_conv3x3_dgrad", L.ptr(dy), L.ptr(w), L.ptr(dx), B, H, W, C, Cout, stride, L.dt(dy), L.stream())
+    return dx
+
+
+_conv_scratch = {}
+
+
+def conv3x3_wgrad(dy, x, dw, db, B, H, W, C, Cout, stride=1):
+    """dw [Cout, 9*C] fp32 += , db [Cout] fp32 += (views of the flat gradient buffer)."""
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    need = L.load().uwu_conv3x3_wgrad_scratch_bytes(C, Cout, B * Ho * Wo)
+    key = dy.device
+    sc = _conv_scratch.get(key)
+    if sc is None or sc.numel() < need:  # one growing split-K scratch per device (launches on a stream are ordered)
+        sc = _conv_scratch[key] = torch.empty(need, device=dy.device, dtype=torch.uint8)
+    L.call("uwu_conv3x3_wgrad", L.ptr(dy), L.ptr(x), L.ptr(dw), L.ptr(db), B, H, W, C, Cout, stride, L.dt(dy), L.ptr(sc),
+           sc.numel(), L.stream())
+
+
 def groupnorm_fwd(x, gamma, beta, B, HW, C, G, eps, silu):
     y = torch.empty_like(x)
     mean = torch.empty(B * G, device=x.device, dtype=torch.float32)

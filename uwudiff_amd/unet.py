@@ -123,19 +123,32 @@ class _LinearFn(torch.autograd.Function):
 class _Conv3x3Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, P, wname, bname, B, H, W_, C, stride):
-        col = ops.im2col3x3(x, B, H, W_, C, stride)
-        y = ops.gemm(col, P.w(wname), bias=P.w32(bname), epilogue=L.EPI_BIAS)
+        Wt = P.w(wname)
+        # implicit GEMM (the ring kernel gathers its activation rows pixel by pixel; no column matrix) where the shape
+        # allows it: bf16, channel counts that are multiples of 32 -- every convolution of the SDXL shape except conv_in
+        implicit = ops.conv3x3_implicit_ok(x, B, H, W_, C, Wt.shape[0], stride)
+        if implicit:
+            y = ops.conv3x3_fwd(x, Wt, P.w32(bname), B, H, W_, C, Wt.shape[0], stride)
+        else:
+            col = ops.im2col3x3(x, B, H, W_, C, stride)
+            y = ops.gemm(col, Wt, bias=P.w32(bname), epilogue=L.EPI_BIAS)
         ctx.save_for_backward(x)
-        ctx.meta = (P, wname, bname, B, H, W_, C, stride)
+        ctx.meta = (P, wname, bname, B, H, W_, C, stride, implicit)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
-        P, wname, bname, B, H, W_, C, stride = ctx.meta
+        P, wname, bname, B, H, W_, C, stride, implicit = ctx.meta
         dy = dy.contiguous()
         Wt = P.w(wname)
         dx = None
+        if implicit:
+            Cout = Wt.shape[0]
+            if ctx.needs_input_grad[0]:
+                dx = ops.conv3x3_dgrad(dy, Wt, B, H, W_, C, Cout, stride)
+            ops.conv3x3_wgrad(dy, x, P.g(wname), P.g(bname), B, H, W_, C, Cout, stride)
+            return (dx,) + (None,) * 8
         if ctx.needs_input_grad[0]:
             dcol = ops.gemm(dy, Wt, trans_b=True)
             dx = ops.col2im3x3(dcol, B, H, W_, C, stride)
