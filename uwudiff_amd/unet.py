@@ -116,7 +116,7 @@ class _LinearFn(torch.autograd.Function):
         N = W.shape[0]
         dx = ops.gemm(dy, W, trans_b=True) if ctx.needs_input_grad[0] else None
         # dW += dy^T x and db += colsum(dy) in one launch where the streaming kernel takes the shape
-        ops.gemm_wgrad(dy, x, P.g(wname), blocks=_wgrad_blocks(M, N, K), bias_grad=P.g(bname) if bname else None)
+        ops.gemm_wgrad_shared(dy, x, P.g(wname), blocks=_wgrad_blocks(M, N, K), bias_grad=P.g(bname) if bname else None)
         return dx, None, None, None, None, None
 
 
