@@ -62,10 +62,12 @@ class DMTrainer(BaseTrainer):
             raise NotImplementedError("LyCORIS adapters are out of scope of the MI355X hot path")
         self.unet = load_any(model_config["unet"])
         self.te = load_any(model_config["te"]) if model_config.get("te") is not None else None
-        if model_config.get("vae") is not None:
-            raise NotImplementedError("VAE encoding needs hub weights (diffusers.AutoencoderKL); train on latents "
-                                      "with `vae: null` as configs/demo_training_latent.yaml does")
-        self.vae = None
+        # trainer.py:136,241-244: any frozen module with `.encode(x).latent_dist.sample()` (diffusers.AutoencoderKL needs
+        # hub weights; `uwudiff_amd.conditioning.SyntheticVAE` is the offline stand-in).  The (x - mean) / std step that
+        # follows the encoder is folded into the loss's q-sample kernel.
+        self.vae = load_any(model_config["vae"]) if model_config.get("vae") is not None else None
+        if self.vae is not None:
+            self.vae.requires_grad_(False).eval()
         self.te_use_normed_ctx = te_use_normed_ctx
         self.vae_std, self.vae_mean = vae_std, vae_mean or 0
         self.register_buffer("ema_loss", torch.tensor(0.0))
@@ -81,12 +83,18 @@ class DMTrainer(BaseTrainer):
         else:
             self.loss = instantiate_any(loss_config)
         self.n_diffusion_time_steps = self.loss.n_diffusion_time_steps
+        if self.vae is not None and self.vae_std is not None:
+            if not hasattr(self.loss, "set_latent_normalisation"):
+                raise NotImplementedError("vae_mean / vae_std need a loss with set_latent_normalisation (duwu.loss.*)")
+            self.loss.set_latent_normalisation(self.vae_mean, self.vae_std)
 
     # trainer.py:233-261
     def get_latent_and_conditioning(self, batch):
         x, captions, tokenizer_outputs, added_cond, cross_attn_kwargs = batch
         ctx = attn_mask = pooled = None
         with torch.no_grad():
+            if self.vae is not None:  # trainer.py:241-243 (the normalisation of :244 happens inside the loss kernel)
+                x = self.vae.encode(x).latent_dist.sample()
             if self.te is not None:
                 embedding, normed, pooled, attn_mask = self.te(tokenizer_outputs)
                 ctx = normed if self.te_use_normed_ctx else embedding

@@ -75,6 +75,18 @@ int uwu_rf_time_to_sigma(const float* u01, float sigma_max, const float* log_sig
 int uwu_qsample(const float* x, const float* noise, const float* coef, int B, int64_t n, float* noisy,
                 void* noisy_bf16, void* stream);
 
+/* The same with the VAE latent normalisation of trainer.py:241-244 folded in: x_norm = (x - vae_mean) / vae_std
+ * (written once: it is the clean latent the loss compares against), noisy = (x_norm + noise*sigma_b)*(sigma_b^2+1)^-1/2. */
+int uwu_qsample_norm(const float* x, const float* noise, const float* coef, int B, int64_t n, float vae_mean,
+                     float vae_std, float* x_norm, float* noisy, void* stream);
+
+/* Conditioning front-end, text_encoders.py:196-262: place one text encoder's hidden states src [B,S,F] (fp32 / bf16),
+ * times its attention mask [B,S] (int64, may be NULL: zero_for_padding off or no mask), into the zero-filled context
+ * out [B,S_total,F_total] (fp32) at sequence offset s_off (its concat bucket) and feature offset f_off (its place
+ * inside the bucket; narrower buckets stay zero-padded on the feature axis). */
+int uwu_ctx_place(const void* src, int dtype, const int64_t* mask, float* out, int B, int S, int F, int S_total,
+                  int F_total, int s_off, int f_off, void* stream);
+
 /* Fused prediction conversion + target + per-sample weighted MSE + d loss/d model_output,
  * diffusion.py:177-193 (+ :100-139) and rectified_flow.py:79-96.
  *   xt: the tensor the reference passes as `xt` (clean x for DiffusionLoss :177, noisy for RF :80).

@@ -1,0 +1,87 @@
+"""Conditioning front-end on the device:
+  * ``ConcatTextEncoders.forward`` bucket / concat / pad / mask / pooled assembly against fixtures produced by the
+    REFERENCE's own forward (oracle/make_golden_te.py ran /root/reference/src/duwu/modules/text_encoders.py:139-264 over
+    the same synthetic text models) -- bit-exact: the assembly only moves and masks values;
+  * the VAE latent normalisation of trainer.py:241-244 fused into the q-sample kernel."""
+import pytest
+import torch
+
+from tests.golden_util import load, names
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", names("te_"))
+def test_concat_text_encoders_matches_reference_forward(name):
+    from uwudiff_amd.conditioning import ConcatTextEncoders, SyntheticTextModel
+
+    meta, d = load(name)
+    models = [(SyntheticTextModel(m["hidden"], m["seed"]), m["config"]) for m in meta["models"]]
+    te = ConcatTextEncoders(tokenizers=[], text_model_and_configs=models, zero_for_padding=meta["zero_for_padding"]).cuda()
+    tok = {"input_ids": d["input_ids"], "attention_mask": d["attention_mask"]}
+    emb, normed, pooled, mask = te([tok] * len(models))
+    assert torch.equal(emb.cpu(), d["embedding"])
+    assert torch.equal(normed.cpu(), d["normed"])
+    assert torch.equal(pooled.cpu(), d["pooled"])
+    if meta["has_mask"]:
+        assert torch.equal(mask.cpu(), d["mask"])
+    else:
+        assert mask is None
+
+
+def test_t5_style_encoder_joins_a_second_bucket():
+    """SD3-like layout: two CLIP-style encoders in bucket 0, a T5-style one (no pooled output) in bucket 1.  The reference
+    crashes on this path (``pooled_embedding.to`` on None, text_encoders.py:196) -- not reproduced; checked against the
+    reference's stated layout (features of bucket 0 concatenated, the narrower bucket zero-padded, buckets on the sequence
+    axis)."""
+    from uwudiff_amd.conditioning import ConcatTextEncoders, SyntheticTextModel, SyntheticTokenizer
+
+    ms = [SyntheticTextModel(48, 1), SyntheticTextModel(80, 2), SyntheticTextModel(64, 3, kind="t5")]
+    cfgs = [dict(concat_bucket=0, use_pooled=True), dict(concat_bucket=0, use_pooled=True), dict(concat_bucket=1, need_mask=True)]
+    te = ConcatTextEncoders(tokenizers=["a", "b", "c"], text_model_and_configs=list(zip(ms, cfgs))).cuda()
+    tok = SyntheticTokenizer()(["a red fox", "two"])
+    emb, normed, pooled, mask = te([tok] * 3)
+    assert emb.shape == (2, 154, 128) and pooled.shape == (2, 128) and mask.shape == (2, 154)
+    am = tok["attention_mask"].cuda()
+    h2 = ms[2](tok["input_ids"].cuda(), output_hidden_states=True)[1][-1] * am[..., None]
+    assert torch.equal(emb[:, 77:, :64], h2) and float(emb[:, 77:, 64:].abs().max()) == 0.0
+    assert torch.equal(mask[:, :77], torch.ones(2, 77, device="cuda", dtype=torch.long)) and torch.equal(mask[:, 77:], am)
+
+
+def test_vae_latent_normalisation_is_fused_into_qsample():
+    from uwudiff_amd.objective import DiffusionLoss
+    from uwudiff_amd.scheduler import EulerDiscreteScheduler
+
+    torch.manual_seed(0)
+    x, noise = torch.randn(4, 4, 8, 8) * 3 + 1, torch.randn(4, 4, 8, 8)
+    t = torch.tensor([0, 10, 500, 999])
+    out = torch.randn(4, 4, 8, 8)
+
+    class Leaf(torch.nn.Module):
+        def forward(self, noisy, ts, **kw):
+            self.seen = noisy
+            return (out.cuda(),)
+
+    mean, std = 0.7, 2.5
+    plain, fused = DiffusionLoss(EulerDiscreteScheduler.from_pretrained("sdxl")), DiffusionLoss(EulerDiscreteScheduler.from_pretrained("sdxl"))
+    fused.set_latent_normalisation(mean, std)
+    u1, u2 = Leaf(), Leaf()
+    plain.inject(noise=noise.cuda(), timesteps=t.cuda())
+    l1, a1 = plain(((x - mean) / std).cuda(), u1)        # what the reference does: normalise, then the loss
+    fused.inject(noise=noise.cuda(), timesteps=t.cuda())
+    l2, a2 = fused(x.cuda(), u2)
+    torch.testing.assert_close(a2.noisy_latent, a1.noisy_latent, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(a2.target, a1.target, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(l2, l1, rtol=1e-5, atol=1e-7)
+
+
+def test_trainer_vae_slot_encodes_and_normalises():
+    from duwu.trainer import DMTrainer
+
+    cfg = {"unet": {"_target_": "uwudiff_amd.dit.DiT.from_config", "config": {"depth": 1, "hidden": 128, "heads": 2, "sample_size": 8}},
+           "te": None, "vae": {"_target_": "uwudiff_amd.conditioning.SyntheticVAE"}}
+    tr = DMTrainer(cfg, vae_std=0.5, vae_mean=0.1, use_warm_up=False).cuda()
+    batch = (torch.randn(2, 3, 64, 64).cuda(), ["", ""], [], {}, {})
+    out = tr.training_step(batch, 0)
+    assert out["aux_output"].noisy_latent.shape == (2, 4, 8, 8) and torch.isfinite(out["loss"])
+    assert tr.loss._latent_norm == (0.1, 0.5)

@@ -146,3 +146,22 @@ def test_dit_state_dict_roundtrip_with_oracle_names():
         assert torch.equal(sd[k], v)
     o2 = DiTOracle(**cfg)
     o2.load_state_dict(sd)
+
+
+@pytest.mark.parametrize("name", ["te_sdxl", "te_sdxl_zero_pad_mask", "te_two_buckets"])
+def test_concat_text_encoders_host_assembly_matches_reference_golden(name):
+    """The bucket / concat / pad / mask / pooled assembly (reference text_encoders.py:139-264) on host tensors, against the
+    fixtures the reference's own ``ConcatTextEncoders.forward`` produced (oracle/make_golden_te.py); the device path is
+    tests/test_conditioning_gpu.py."""
+    from tests.golden_util import load
+    from uwudiff_amd.conditioning import ConcatTextEncoders, SyntheticTextModel
+
+    meta, d = load(name)
+    models = [(SyntheticTextModel(m["hidden"], m["seed"]), m["config"]) for m in meta["models"]]
+    te = ConcatTextEncoders(tokenizers=[], text_model_and_configs=models, zero_for_padding=meta["zero_for_padding"])
+    tok = {"input_ids": d["input_ids"], "attention_mask": d["attention_mask"]}
+    emb, normed, pooled, mask = te([tok] * len(models))
+    assert torch.equal(emb, d["embedding"]) and torch.equal(normed, d["normed"]) and torch.equal(pooled, d["pooled"])
+    assert (mask is None) == (not meta["has_mask"])
+    if mask is not None:
+        assert torch.equal(mask, d["mask"])

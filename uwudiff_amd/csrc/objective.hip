@@ -80,6 +80,45 @@ __global__ void qsample_kernel(const float* __restrict__ x, const float* __restr
   }
 }
 
+// trainer.py:241-244 fused into the forward process: x_n = (x - vae_mean) / vae_std is what the loss sees as the clean
+// latent, so it is written once here (the loss kernel reads it back) together with noisy = (x_n + noise sigma) scale.
+__global__ void qsample_norm_kernel(const float* __restrict__ x, const float* __restrict__ noise,
+                                    const float* __restrict__ coef, int64_t n4, int64_t total4, float mean, float inv_std,
+                                    float* __restrict__ x_norm, float* __restrict__ noisy) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < total4; i += stride) {
+    int b = (int)(i / n4);
+    float sigma = coef[4 * b];
+    float scale = 1.f / sqrtf(sigma * sigma + 1.f);
+    f32x4 xv = load4(x + 4 * i), nv = load4(noise + 4 * i), xn, o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      xn[j] = (xv[j] - mean) * inv_std;
+      o[j] = (xn[j] + nv[j] * sigma) * scale;
+    }
+    store4(x_norm + 4 * i, xn);
+    store4(noisy + 4 * i, o);
+  }
+}
+
+// text_encoders.py:196-262: one encoder's [B, S, F] hidden states land in the [B, S_total, F_total] context at
+// (sequence offset of its bucket, feature offset inside the bucket), times its attention mask (zero_for_padding).
+// The destination is zero-filled beforehand, which is the reference's F.pad of the narrower buckets.
+template <typename T>
+__global__ void ctx_place_kernel(const T* __restrict__ src, const long long* __restrict__ mask, float* __restrict__ out,
+                                 int B, int S, int F, int S_total, int F_total, int s_off, int f_off) {
+  const int64_t total = (int64_t)B * S * F, step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+    const int f = (int)(i % F);
+    const int64_t bs = i / F;
+    const int sidx = (int)(bs % S), b = (int)(bs / S);
+    float v = to_f32(src[i]);
+    if (mask) v *= (float)mask[bs];
+    out[((int64_t)b * S_total + s_off + sidx) * F_total + f_off + f] = v;
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // diffusion.py:100-125 elementwise, in the reference's own operation order
 __device__ __forceinline__ void x0_eps(int ptype, float xt, float out, float s, float scales, float& x0,
@@ -262,6 +301,36 @@ extern "C" int uwu_qsample(const float* x, const float* noise, const float* coef
   hipLaunchKernelGGL(qsample_kernel, dim3(ew_grid(total4, 256)), dim3(256), 0, (hipStream_t)stream, x, noise, coef,
                      n / 4, total4, noisy, (bf16_t*)noisy_bf16);
   UWU_LAUNCH_CHECK("qsample");
+  return UWU_OK;
+}
+
+extern "C" int uwu_qsample_norm(const float* x, const float* noise, const float* coef, int B, int64_t n, float vae_mean,
+                                float vae_std, float* x_norm, float* noisy, void* stream) {
+  UWU_CHECK_ARG(x && noise && coef && noisy && x_norm, "qsample_norm: null pointer");
+  UWU_CHECK_ARG(B > 0 && n > 0 && n % 4 == 0, "qsample_norm: n=%lld must be a positive multiple of 4", (long long)n);
+  UWU_CHECK_ARG(vae_std != 0.f, "qsample_norm: vae_std must be non-zero");
+  int64_t total4 = (int64_t)B * n / 4;
+  hipLaunchKernelGGL(qsample_norm_kernel, dim3(ew_grid(total4, 256)), dim3(256), 0, (hipStream_t)stream, x, noise, coef,
+                     n / 4, total4, vae_mean, 1.f / vae_std, x_norm, noisy);
+  UWU_LAUNCH_CHECK("qsample_norm");
+  return UWU_OK;
+}
+
+extern "C" int uwu_ctx_place(const void* src, int dtype, const int64_t* mask, float* out, int B, int S, int F, int S_total,
+                             int F_total, int s_off, int f_off, void* stream) {
+  UWU_CHECK_ARG(src && out && B > 0 && S > 0 && F > 0, "ctx_place: bad argument");
+  UWU_CHECK_ARG(s_off >= 0 && f_off >= 0 && s_off + S <= S_total && f_off + F <= F_total, "ctx_place: block outside the context");
+  const int grid = ew_grid((int64_t)B * S * F, 256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == UWU_F32)
+    hipLaunchKernelGGL((ctx_place_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)src, (const long long*)mask, out, B,
+                       S, F, S_total, F_total, s_off, f_off);
+  else if (dtype == UWU_BF16)
+    hipLaunchKernelGGL((ctx_place_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)src, (const long long*)mask, out,
+                       B, S, F, S_total, F_total, s_off, f_off);
+  else
+    UWU_CHECK_ARG(false, "ctx_place: bad dtype");
+  UWU_LAUNCH_CHECK("ctx_place");
   return UWU_OK;
 }
 

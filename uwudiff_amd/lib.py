@@ -42,6 +42,8 @@ _SIGS = {
     "uwu_schedule_gather": (c_int, [P, P, P, P, c_int, c_int, c_int, c_float, c_int, P, P]),
     "uwu_rf_time_to_sigma": (c_int, [P, c_float, P, c_int, c_int, P, P, P]),
     "uwu_qsample": (c_int, [P, P, P, c_int, c_int64, P, P, P]),
+    "uwu_qsample_norm": (c_int, [P, P, P, c_int, c_int64, c_float, c_float, P, P, P]),
+    "uwu_ctx_place": (c_int, [P, c_int, P, P] + [c_int] * 7 + [P]),
     "uwu_loss_fwd_bwd": (c_int, [P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int64, P, P, P, P, P, P]),
     "uwu_scale_inplace": (c_int, [P, c_int, c_int64, P, P]),
     "uwu_sampler_step": (c_int, [P, P, P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, P]),

@@ -87,6 +87,7 @@ class DiffusionLoss(nn.Module):
         self.n_diffusion_time_steps = self.scheduler.config.num_train_timesteps
         self._tables = {}
         self._inject = None
+        self._latent_norm = None  # (vae_mean, vae_std): trainer.py:241-244, folded into the q-sample kernel
 
     # diffusion.py:42-51
     def prepare_scheduler_for_custom_training(self):
@@ -94,6 +95,11 @@ class DiffusionLoss(nn.Module):
             return
         abar = self.scheduler.alphas_cumprod
         self.scheduler.all_snr = (torch.sqrt(abar) / torch.sqrt(1.0 - abar)) ** 2
+
+    def set_latent_normalisation(self, mean=0.0, std=None):
+        """``x <- (x - vae_mean) / vae_std`` (reference trainer.py:241-244, applied there between the VAE and the loss) as a
+        fused pre-step of the forward process: one kernel writes the normalised latent and the noisy latent."""
+        self._latent_norm = None if std is None else (float(mean or 0.0), float(std))
 
     def inject(self, noise=None, timesteps=None, u01=None):
         """One-shot RNG injection for parity runs (CPU and HIP generators differ)."""
@@ -158,6 +164,16 @@ class DiffusionLoss(nn.Module):
                L.stream())
         return noisy
 
+    def _qsample_normed(self, x, noise, coef):
+        """(clean latent the loss sees, noisy latent); with a latent normalisation set both come out of one kernel."""
+        if self._latent_norm is None:
+            return x, self._qsample(x, noise, coef)
+        mean, std = self._latent_norm
+        xn, noisy = torch.empty_like(x), torch.empty_like(x)
+        L.call("uwu_qsample_norm", L.ptr(x), L.ptr(noise), L.ptr(coef), x.shape[0], x[0].numel(), mean, std, L.ptr(xn),
+               L.ptr(noisy), L.stream())
+        return xn, noisy
+
     def _noise_like(self, x):
         n = self._take_injected("noise")
         if n is None:
@@ -172,7 +188,7 @@ class DiffusionLoss(nn.Module):
         noise = self._noise_like(x)  # drawn before the timesteps, as diffusion.py:75-76
         timesteps, coef = self.sample_timesteps_and_sigmas(x)
         self._inject = None
-        noisy = self._qsample(x, noise, coef)
+        x, noisy = self._qsample_normed(x, noise, coef)
         model_output = unet(noisy, timesteps, **unet_kwargs)[0]
         # NB the reference hands the *clean* x to get_prediction_for_training as `xt` (diffusion.py:177)
         loss, losses, pred, target = _FusedLoss.apply(model_output, x, noise, x, coef, pt, tt, False)
@@ -235,7 +251,7 @@ class RectifiedFlowLoss(DiffusionLoss):
         x, noises = self.get_x0_and_noises(x)
         timesteps, coef = self.sample_timesteps_and_sigmas(x)
         self._inject = None
-        noisy = self._qsample(x, noises, coef)
+        x, noisy = self._qsample_normed(x, noises, coef)
         model_output = unet(noisy, timesteps, **unet_kwargs)[0]
         loss, losses, pred, target = _FusedLoss.apply(model_output, x, noises, noisy, coef, pt, L.PT["rectified_flow"],
                                                       True)
