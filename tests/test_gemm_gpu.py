@@ -310,7 +310,11 @@ def test_gemm_tr_random(monkeypatch):
     torch.testing.assert_close(out, want, rtol=1e-4, atol=2e-2)
 
 
-@pytest.mark.parametrize("M,N,K", [(1536, 384, 65536), (1152, 384, 8192), (384, 1536, 4096), (200, 264, 2048)])
+# (N or M a multiple of 384 with K >= 4096 and a scratch: the wide one-workgroup-per-CU kernel, 192x384 / 384x192 tiles,
+#  half-used last sub-image, ragged last row / column tile, 4-stage ring shorter than the K loop and longer)
+@pytest.mark.parametrize("M,N,K", [(1536, 384, 65536), (1152, 384, 8192), (384, 1536, 4096), (200, 264, 2048),
+                                   (384, 384, 6144), (200, 384, 4096), (384, 264, 4096), (768, 768, 8192),
+                                   (1152, 1152, 4096), (4608, 1152, 4096)])
 def test_gemm_wgrad_scratch_path(M, N, K):
     """uwu_gemm_wgrad with split-K scratch (slices + reduce kernel) == exact matmul on integers, on top of existing C."""
     from uwudiff_amd import ops

@@ -1344,6 +1344,148 @@ __global__ void __launch_bounds__(256, 2) gemm_tr_kernel(const GemmArgs g) {
     }
 }
 
+// ---- wide streaming weight gradient: 192 x 384 or 384 x 192 tile, ONE 8-wave workgroup per CU ------------------------------
+// Why: all tiles of a K slice read the same rows, so the UNIQUE bytes a launch has in flight are only
+// (slices running at once) x (stages in flight) x (32 rows x (M + N) x 2 B).  With 256x128 tiles the 18 tiles of an fc1 slice
+// leave room for ~3.5 slices per XCD: ~6 MB in flight chip-wide, which at ~2.6 us of loaded HBM latency is the 2.3-2.6 TB/s
+// the 256x128 kernel measures (a third of the HBM rate, although it only READS).  A tile that spans the whole 384-wide
+// operand needs 8 tiles per slice: 4 slices per XCD at one workgroup per CU, a 4-stage ring (3 in flight), every operand row
+// crosses L2 -> LDS once per 192 (384) output rows instead of once per 128 -- ~2.5x the unique bytes in flight.
+// Structure as gemm_tr_kernel (K-major operands untouched in LDS, ds_read_b64_tr_b16 fragments, split-K partials to a
+// scratch + splitk_reduce_kernel, fused bias gradient); waves WM x WN, wave tile 96 x 96 (FI = FJ = 6: 144 accumulator
+// registers; a 256-row tile needs 192 and spilled).  The 192-wide operand fills one and a half [32 k][128 x] sub-images: the
+// DMA lanes of the unused half are masked off.
+constexpr int W_NSUB = 5;                 // sub-images [32 k][128 x] per stage: NA for A, 5 - NA for B
+constexpr int W_STAGE = W_NSUB * T_SUB;   // 40 KB
+template <int WM, int WN, int FI, int FJ, int NST>
+__global__ void __launch_bounds__(512, 2) gemm_trw_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef bf16_t T;
+  static_assert(WM * WN == 8, "8 waves");
+  constexpr int TBM = 16 * FI * WM, TBN = 16 * FJ * WN;
+  constexpr int NA = (TBM + 127) / 128, NB = (TBN + 127) / 128;
+  static_assert(NA + NB == W_NSUB, "five sub-images per stage");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int nblk = g.tiles_m * g.tiles_n;
+  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  const int zsl = xcd + 8 * (loc / nblk), tile = loc % nblk;
+  if (zsl >= g.wide) return;  // uniform per block
+  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  const int m0 = tm * TBM, n0 = tn * TBN;
+  const int s_begin = zsl * g.k_tiles_per_split;
+  int s_end = s_begin + g.k_tiles_per_split;
+  if (s_end > (g.K >> 5)) s_end = g.K >> 5;
+  const int ns = s_end - s_begin;
+  if (ns <= 0) return;  // uniform per block
+
+  // ---- DMA: wave w moves rows 4w .. 4w+3 of every sub-image (piece q = sub-image q)
+  const int drow = lane >> 4;
+  const int dchunk = (lane & 15) ^ (((drow & 3) << 2) | (wave & 3));
+  const T* src[W_NSUB];
+  bool live[W_NSUB];  // lanes whose 8 columns lie inside the tile (the last sub-image of a 192-wide operand is half used)
+#pragma unroll
+  for (int q = 0; q < W_NSUB; ++q) {
+    const bool isA = q < NA;
+    const int xl = 128 * (isA ? q : q - NA) + 8 * dchunk;  // column inside the tile
+    live[q] = xl < (isA ? TBM : TBN);
+    int x = (isA ? m0 : n0) + xl;
+    const int X = isA ? g.M : g.N;
+    if (x > X - 8) x = X - 8;  // columns past the operand: clamped (their products are never stored)
+    src[q] = static_cast<const T*>(isA ? g.A : g.B) + (int64_t)(s_begin * 32 + 4 * wave + drow) * (isA ? g.lda : g.ldb) + x;
+  }
+  const int64_t stepA = (int64_t)32 * g.lda, stepB = (int64_t)32 * g.ldb;
+  auto issue = [&](int s) {
+    char* st = smem + (s % NST) * W_STAGE + wave * 1024;
+#pragma unroll
+    for (int q = 0; q < W_NSUB; ++q)
+      if (live[q])  // (EXEC-masked DMA: the other lanes' LDS slots keep stale bytes no fragment reads)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[q] + s * (q < NA ? stepA : stepB)),
+                                         (__attribute__((address_space(3))) void*)(st + q * T_SUB), 16, 0, 0);
+  };
+
+  f32x4 acc[FI][FJ];
+#pragma unroll
+  for (int i = 0; i < FI; ++i)
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // fused bias gradient (column sums of A = dY): the waves of one wave row share its FI row fragments
+  const bool do_sum = g.bias != nullptr && tn == 0;  // wave-uniform
+  constexpr int FS = (FI + WN - 1) / WN;  // row fragment fi is summed by wave column fi % WN, in its slot fi / WN
+  f32x4 sacc[FS];
+#pragma unroll
+  for (int i = 0; i < FS; ++i) sacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const uint4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+
+  // fragment g of an operand (16 columns each, 8 per sub-image): sub-image g >> 3, chunk bits (g & 7) << 5
+  const unsigned smem_base = (unsigned)(size_t)((const __attribute__((address_space(3))) char*)smem);
+  const unsigned t0 = tr_lane_base(lane, 0, 0), t1 = tr_lane_base(lane, 1, 0);
+  auto frag = [&](unsigned sb, int gidx) {
+    const unsigned sub = sb + (unsigned)((gidx >> 3) * T_SUB), fl = (unsigned)((gidx & 7) << 5);
+    const uint2 lo = t_read_tr<0>(sub + (t0 ^ fl)), hi = t_read_tr<0>(sub + (t1 ^ fl));
+    return uint4{lo.x, lo.y, hi.x, hi.y};
+  };
+  const int ga0 = FI * wm, gb0 = 8 * NA + FJ * wn;  // (16-column fragment index counted over the operand's sub-images)  // first fragment index of this wave in A / in B (B sub-images follow A's)
+
+  constexpr int AHEAD = NST - 1;
+#pragma unroll
+  for (int s = 0; s < AHEAD; ++s)
+    if (s < ns) issue(s);
+  constexpr int GI = FI / 2;  // A fragments per half
+  for (int s = 0; s < ns; ++s) {
+    // K-step s has landed once at most the pieces of the (up to AHEAD - 1) younger steps are outstanding
+    const int younger = ns - 1 - s < AHEAD - 1 ? ns - 1 - s : AHEAD - 1;
+    if (younger >= 2) r_wait_vm<2 * W_NSUB>();
+    else if (younger == 1) r_wait_vm<W_NSUB>();
+    else r_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();  // everybody's pieces of step s; everybody is done reading stage (s - 1) % NST
+    if (s + AHEAD < ns) issue(s + AHEAD);
+    const unsigned sb = smem_base + (unsigned)((s % NST) * W_STAGE);
+    uint4 bf[FJ], af[GI];
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) bf[j] = frag(sb, gb0 + j);
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+      for (int i = 0; i < GI; ++i) af[i] = frag(sb, ga0 + GI * hh + i);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < GI; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) mma_frag<T>(bf[j], af[i], acc[GI * hh + i][j]);
+      if (do_sum) {
+#pragma unroll
+        for (int i = 0; i < GI; ++i) {
+          const int fi = GI * hh + i;
+          if (fi % WN == wn) mma_frag<T>(ones, af[i], sacc[fi / WN]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (do_sum) {
+    float* bg = const_cast<float*>(g.bias);
+#pragma unroll
+    for (int i = 0; i < FS; ++i) {  // D[n][m]: column m = fr on the lane, every row equal
+      const int fi = i * WN + wn;
+      const int m = m0 + wm * 16 * FI + 16 * fi + fr;
+      if (fi < FI && fq == 0 && m < g.M) atomicAdd(bg + m, sacc[i][0]);
+    }
+  }
+  float* P = static_cast<float*>(g.C2) + (int64_t)zsl * g.M * g.N;
+#pragma unroll
+  for (int i = 0; i < FI; ++i) {
+    const int m = m0 + wm * 16 * FI + 16 * i + fr;
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) {
+      const int n = n0 + wn * 16 * FJ + 16 * j + 4 * fq;
+      if (m < g.M && n < g.N) store4(P + (int64_t)m * g.N + n, acc[i][j]);
+    }
+  }
+}
+
 // ---- fp8 (OCP e4m3 / e5m2) operands on the block-scaled MFMA: BASELINE config 5 ("fp8 MFMA GEMMs") -----------------------
 // v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (E8M0 = 127) runs at twice the bf16 rate (MI355X_MICROARCH.md,
 // Matrix cores) -- the non-scaled fp8 MFMAs only reach the bf16 rate.  ONE kernel shape serves forward, input gradient and
@@ -1647,6 +1789,59 @@ int launch_tr(GemmArgs g, void* scratch, size_t scratch_bytes, hipStream_t st) {
   }
   prof.done(CONVW ? UWU_PROF_CONV : UWU_PROF_GEMM_WGRAD, 0, 2.0 * g.M * g.N * g.K, ((double)g.M * g.K + (double)g.N * g.K) * 2 + (double)g.M * g.N * 4);
   UWU_LAUNCH_CHECK("gemm_tr");
+  return UWU_OK;
+}
+
+// wide weight-gradient kernel: K slices in groups of 8 (one group per XCD), one workgroup per CU
+int trw_split(int tiles, int steps) {
+  int per_xcd = 32 / tiles;
+  if (per_xcd < 1) per_xcd = 1;
+  int split = 8 * per_xcd;
+  while (split > 8 && split * 8 > steps) split -= 8;  // keep >= 8 K-steps per slice
+  if (split > steps) split = steps;
+  return split < 1 ? 1 : split;
+}
+// 0 = not taken, 1 = 192 x 384 tiles, 2 = 384 x 192 tiles.  UWU_GEMM_TRW=0 turns it off (A/B comparisons).
+int pick_trw(const GemmArgs& g) {
+  const char* e = getenv("UWU_GEMM_TRW");
+  if (e && e[0] == '0') return 0;
+  if (g.K % 32 || g.K < 4096 || g.M % 8 || g.N % 8) return 0;
+  if ((((uintptr_t)g.A | (uintptr_t)g.B) & 15) || g.lda % 8 || g.ldb % 8) return 0;
+  if (g.N % 384 == 0 && g.M >= 192) return 1;
+  if (g.M % 384 == 0 && g.N >= 192) return 2;
+  return 0;
+}
+size_t trw_scratch_bytes(int M, int N, int K, int kind) {
+  const int tiles = kind == 1 ? ((M + 191) / 192) * (N / 384) : (M / 384) * ((N + 191) / 192);
+  return (size_t)trw_split(tiles, K / 32) * M * N * sizeof(float);
+}
+template <int WM, int WN, int FI, int FJ>
+int launch_trw(GemmArgs g, void* scratch, hipStream_t st) {
+  constexpr int NST = 4;
+  auto kern = gemm_trw_kernel<WM, WN, FI, FJ, NST>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, NST * W_STAGE);
+    attr_done = true;
+  }
+  g.tiles_m = (g.M + 16 * FI * WM - 1) / (16 * FI * WM);
+  g.tiles_n = (g.N + 16 * FJ * WN - 1) / (16 * FJ * WN);
+  const int tiles = g.tiles_m * g.tiles_n, steps = g.K / 32;
+  int split = trw_split(tiles, steps);
+  g.k_tiles_per_split = (steps + split - 1) / split;
+  split = (steps + g.k_tiles_per_split - 1) / g.k_tiles_per_split;
+  g.wide = split;
+  g.C2 = scratch;
+  const int grid = 8 * tiles * ((split + 7) / 8);
+  UwuProfScope prof(st);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), NST * W_STAGE, st, g);
+  const int64_t quads = (int64_t)g.M * g.N / 4;
+  int rg = (int)((quads + 255) / 256);
+  if (rg > 4096) rg = 4096;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, st, static_cast<const float*>(scratch),
+                     static_cast<float*>(g.C), g.M, g.N, g.ldc, split);
+  prof.done(UWU_PROF_GEMM_WGRAD, 0, 2.0 * g.M * g.N * g.K, ((double)g.M * g.K + (double)g.N * g.K) * 2 + (double)g.M * g.N * 4);
+  UWU_LAUNCH_CHECK("gemm_trw");
   return UWU_OK;
 }
 // K-major x K-major accumulate (the weight gradients): 0 = keep the 128x128 kernel, 1 = 256x128, 2 = 128x256
@@ -2023,7 +2218,10 @@ extern "C" size_t uwu_gemm_wgrad_scratch_bytes(int M, int N, int K) {
   // the larger of the two tile orientations' slice counts (pick_tr chooses by padding)
   const int t1 = ((M + 255) / 256) * ((N + 127) / 128), t2 = ((M + 127) / 128) * ((N + 255) / 256);
   const int s1 = tr_split(t1, K / 32), s2 = tr_split(t2, K / 32);
-  return (size_t)(s1 > s2 ? s1 : s2) * M * N * sizeof(float);
+  size_t b = (size_t)(s1 > s2 ? s1 : s2) * M * N * sizeof(float);
+  if (N % 384 == 0 && trw_scratch_bytes(M, N, K, 1) > b) b = trw_scratch_bytes(M, N, K, 1);
+  if (M % 384 == 0 && trw_scratch_bytes(M, N, K, 2) > b) b = trw_scratch_bytes(M, N, K, 2);
+  return b;
 }
 
 extern "C" int uwu_gemm_wgrad(const void* A, const void* B, float* C, float* bias_grad, int M, int N, int K, int lda,
@@ -2037,6 +2235,12 @@ extern "C" int uwu_gemm_wgrad(const void* A, const void* B, float* C, float* bia
     GemmArgs g{};
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.epi = UWU_EPI_ACCUM;
     g.bias = bias_grad;
+    const int trw = pick_trw(g);
+    if (trw && scratch && (((uintptr_t)C | (uintptr_t)scratch) & 15) == 0 && ldc % 4 == 0 &&
+        scratch_bytes >= trw_scratch_bytes(M, N, K, trw)) {
+      if (trw == 1) return launch_trw<2, 4, 6, 6>(g, scratch, (hipStream_t)stream);
+      return launch_trw<4, 2, 6, 6>(g, scratch, (hipStream_t)stream);
+    }
     const int tr = pick_tr(g);
     if (tr == 1) return launch_tr<8, 4>(g, scratch, scratch_bytes, (hipStream_t)stream);
     if (tr == 2) return launch_tr<4, 8>(g, scratch, scratch_bytes, (hipStream_t)stream);
