@@ -1357,6 +1357,20 @@ __global__ void __launch_bounds__(256, 2) gemm_tr_kernel(const GemmArgs g) {
 // DMA lanes of the unused half are masked off.
 constexpr int W_NSUB = 5;                 // sub-images [32 k][128 x] per stage: NA for A, 5 - NA for B
 constexpr int W_STAGE = W_NSUB * T_SUB;   // 40 KB
+// Who waits for what in this kernel (at ~250 VGPRs the compiler copies registers around, and it believes an inline-asm
+// ds_read has delivered at its #ASMEND -- a copy it placed between such a read and the hand-written lgkmcnt wait carried
+// the PREVIOUS K-step's fragment into the bias MFMA; cdna_hip_programming.md section 5.7 item 1):
+//   * fragment reads are the BUILTIN transposing read, so hipcc counts lgkmcnt itself and may interleave them with MFMAs;
+//   * the LDS-DMA is inline asm (m0 set and restored inside the statement): invisible to hipcc, so it neither waits
+//     vmcnt(0) before the visible reads nor drains the ring at the barrier; its completion is the hand-counted vmcnt wait.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void glds16_asm(const void* gsrc, unsigned lds_dst /* wave-uniform */) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
 template <int WM, int WN, int FI, int FJ, int NST>
 __global__ void __launch_bounds__(512, 2) gemm_trw_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1365,7 +1379,8 @@ __global__ void __launch_bounds__(512, 2) gemm_trw_kernel(const GemmArgs g) {
   constexpr int TBM = 16 * FI * WM, TBN = 16 * FJ * WN;
   constexpr int NA = (TBM + 127) / 128, NB = (TBN + 127) / 128;
   static_assert(NA + NB == W_NSUB, "five sub-images per stage");
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave - wm * WN;
   const int fr = lane & 15, fq = lane >> 4;
   const int nblk = g.tiles_m * g.tiles_n;
@@ -1396,13 +1411,13 @@ __global__ void __launch_bounds__(512, 2) gemm_trw_kernel(const GemmArgs g) {
     src[q] = static_cast<const T*>(isA ? g.A : g.B) + (int64_t)(s_begin * 32 + 4 * wave + drow) * (isA ? g.lda : g.ldb) + x;
   }
   const int64_t stepA = (int64_t)32 * g.lda, stepB = (int64_t)32 * g.ldb;
+  const unsigned smem_base = (unsigned)(size_t)((const __attribute__((address_space(3))) char*)smem);
   auto issue = [&](int s) {
-    char* st = smem + (s % NST) * W_STAGE + wave * 1024;
+    const unsigned st = smem_base + (unsigned)((s % NST) * W_STAGE + wave * 1024);
 #pragma unroll
     for (int q = 0; q < W_NSUB; ++q)
-      if (live[q])  // (EXEC-masked DMA: the other lanes' LDS slots keep stale bytes no fragment reads)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[q] + s * (q < NA ? stepA : stepB)),
-                                         (__attribute__((address_space(3))) void*)(st + q * T_SUB), 16, 0, 0);
+      if (live[q])  // (EXEC-masked DMA: the other lanes' LDS slots keep stale bytes no fragment reads; every wave has live lanes)
+        glds16_asm(src[q] + s * (q < NA ? stepA : stepB), st + q * T_SUB);
   };
 
   f32x4 acc[FI][FJ];
@@ -1410,25 +1425,34 @@ __global__ void __launch_bounds__(512, 2) gemm_trw_kernel(const GemmArgs g) {
   for (int i = 0; i < FI; ++i)
 #pragma unroll
     for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // fused bias gradient (column sums of A = dY): the waves of one wave row share its FI row fragments
+  // fused bias gradient (column sums of A = dY): row fragment fi is summed by wave column fi % WN, in its slot fi / WN
   const bool do_sum = g.bias != nullptr && tn == 0;  // wave-uniform
-  constexpr int FS = (FI + WN - 1) / WN;  // row fragment fi is summed by wave column fi % WN, in its slot fi / WN
+  constexpr int FS = (FI + WN - 1) / WN;
   f32x4 sacc[FS];
 #pragma unroll
   for (int i = 0; i < FS; ++i) sacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   const uint4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
 
-  // fragment g of an operand (16 columns each, 8 per sub-image): sub-image g >> 3, chunk bits (g & 7) << 5
-  const unsigned smem_base = (unsigned)(size_t)((const __attribute__((address_space(3))) char*)smem);
+  // fragment gidx of an operand (16 columns each, 8 per sub-image): sub-image gidx >> 3, chunk bits (gidx & 7) << 5
   const unsigned t0 = tr_lane_base(lane, 0, 0), t1 = tr_lane_base(lane, 1, 0);
-  auto frag = [&](unsigned sb, int gidx) {
-    const unsigned sub = sb + (unsigned)((gidx >> 3) * T_SUB), fl = (unsigned)((gidx & 7) << 5);
-    const uint2 lo = t_read_tr<0>(sub + (t0 ^ fl)), hi = t_read_tr<0>(sub + (t1 ^ fl));
-    return uint4{lo.x, lo.y, hi.x, hi.y};
+  auto rd = [&](unsigned off) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)((__attribute__((address_space(3))) char*)smem + off));
   };
-  const int ga0 = FI * wm, gb0 = 8 * NA + FJ * wn;  // (16-column fragment index counted over the operand's sub-images)  // first fragment index of this wave in A / in B (B sub-images follow A's)
+  auto frag = [&](unsigned stage_off, int gidx) {
+    const unsigned sub = stage_off + (unsigned)((gidx >> 3) * T_SUB), fl = (unsigned)((gidx & 7) << 5);
+    const s16x4 lo = rd(sub + (t0 ^ fl)), hi = rd(sub + (t1 ^ fl));
+    uint4 r;
+    r.x = ((unsigned)(unsigned short)lo[0]) | ((unsigned)(unsigned short)lo[1] << 16);
+    r.y = ((unsigned)(unsigned short)lo[2]) | ((unsigned)(unsigned short)lo[3] << 16);
+    r.z = ((unsigned)(unsigned short)hi[0]) | ((unsigned)(unsigned short)hi[1] << 16);
+    r.w = ((unsigned)(unsigned short)hi[2]) | ((unsigned)(unsigned short)hi[3] << 16);
+    return r;
+  };
+  const int ga0 = FI * wm, gb0 = 8 * NA + FJ * wn;  // (16-column fragment index counted over the operand's sub-images)
 
   constexpr int AHEAD = NST - 1;
+  static_assert(NST == 4, "the vmcnt ladder below is written for three K-steps ahead");
 #pragma unroll
   for (int s = 0; s < AHEAD; ++s)
     if (s < ns) issue(s);
@@ -1439,18 +1463,16 @@ __global__ void __launch_bounds__(512, 2) gemm_trw_kernel(const GemmArgs g) {
     if (younger >= 2) r_wait_vm<2 * W_NSUB>();
     else if (younger == 1) r_wait_vm<W_NSUB>();
     else r_wait_vm<0>();
-    __builtin_amdgcn_s_barrier();  // everybody's pieces of step s; everybody is done reading stage (s - 1) % NST
+    __syncthreads();  // everybody's pieces of step s; everybody is done reading stage (s - 1) % NST
     if (s + AHEAD < ns) issue(s + AHEAD);
-    const unsigned sb = smem_base + (unsigned)((s % NST) * W_STAGE);
+    const unsigned so = (unsigned)((s % NST) * W_STAGE);
     uint4 bf[FJ], af[GI];
 #pragma unroll
-    for (int j = 0; j < FJ; ++j) bf[j] = frag(sb, gb0 + j);
+    for (int j = 0; j < FJ; ++j) bf[j] = frag(so, gb0 + j);
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
-      for (int i = 0; i < GI; ++i) af[i] = frag(sb, ga0 + GI * hh + i);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < GI; ++i) af[i] = frag(so, ga0 + GI * hh + i);
 #pragma unroll
       for (int i = 0; i < GI; ++i)
 #pragma unroll
@@ -1462,7 +1484,6 @@ __global__ void __launch_bounds__(512, 2) gemm_trw_kernel(const GemmArgs g) {
           if (fi % WN == wn) mma_frag<T>(ones, af[i], sacc[fi / WN]);
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
   }
   if (do_sum) {
