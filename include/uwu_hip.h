@@ -297,6 +297,20 @@ int uwu_axial_rope_fwd(const void* x, const float* pos, const float* fh, const f
 int uwu_axial_rope_bwd(const void* x, const void* dy, const float* pos, const float* fh, const float* fw, void* dx,
                        float* dfh, float* dfw, int64_t rows, int H, int d, int ldx, int dtype, void* stream);
 
+/* Axial RoPE folded into self-attention (rope_unet.py:143-153: RoPE on q and k, then SDPA): the attention kernels multiply
+ * q and k by the factor table tab [T, ldt] (fp32; head h's d columns at h*d; shared positions pos [T,2]) while staging
+ * them, so no rotated copy of q / k exists.  bf16, head dim 64, T == Tk a multiple of 64 up to 256 (the DiT shapes).
+ * uwu_attention_rope_bwd returns dq / dk wrt the ROTATED q' / k'; uwu_axial_rope_bwd (x = the raw q / k, dy = those, dx in
+ * place) turns them into the gradients of q / k and of the log-frequencies. */
+int uwu_axial_rope_table(const float* pos, const float* fh, const float* fw, float* tab, int T, int H, int d, int ldt,
+                         void* stream);
+int uwu_attention_rope_fwd(const void* q, const void* k, const void* v, const float* rope_tab, void* o, float* lse, int B,
+                           int T, int H, int d, int ldq, int ldk, int ldv, int ldo, int ldt, float scale, int dtype,
+                           void* stream);
+int uwu_attention_rope_bwd(const void* q, const void* k, const void* v, const float* rope_tab, const void* o, const void* dO,
+                           const float* lse, void* dq, void* dk, void* dv, int B, int T, int H, int d, int ldq, int ldk,
+                           int ldv, int ldo, int ldt, float scale, int dtype, void* stream);
+
 /* ------------------------------------------------------------------ embeddings / layout (a11, a13) */
 
 /* Sinusoidal timestep features [B, dim]: [cos(t*f_i) | sin(t*f_i)], f_i = exp(-ln(max_period)*i/half). */

@@ -50,3 +50,42 @@ def test_axial_rope_backward(dtype):
     t2 = dict(rtol=1e-3, atol=1e-3) if dtype == torch.float32 else dict(rtol=5e-2, atol=0.5)
     torch.testing.assert_close(m.freqs_h.grad.cpu(), fh.grad, **t2)
     torch.testing.assert_close(m.freqs_w.grad.cpu(), fw.grad, **t2)
+
+
+@pytest.mark.parametrize("B,T,H", [(2, 256, 6), (3, 64, 2), (1, 128, 3)])
+def test_rope_fused_into_attention_matches_composed_reference(B, T, H):
+    """rope_unet.py:143-153 composed (RoPE on q and k, then SDPA) in fp32 on the CPU, with the rotation of the reference's
+    rope.py (ref_formula above is pinned by its golden) -- against the attention kernels that rotate q / k while staging
+    them.  Forward, and the gradients wrt q, k, v and both log-frequency tables."""
+    from uwudiff_amd import ops
+    from uwudiff_amd.rope import make_axial_pos
+
+    torch.manual_seed(B * 100 + T)
+    d, D = 64, 64 * H
+    side = int(T ** 0.5) if int(T ** 0.5) ** 2 == T else None
+    pos = make_axial_pos(side, side) if side else make_axial_pos(T // 8, 8)
+    qkv = (torch.randn(B * T, 3 * D) * 0.7).bfloat16()
+    fh = (torch.linspace(1.1, 2.7, d // 4).expand(H, d // 4) + torch.randn(H, d // 4) * 0.05).contiguous()
+    fw = (torch.linspace(1.1, 2.7, d // 4).expand(H, d // 4) + torch.randn(H, d // 4) * 0.05).contiguous()
+    do = (torch.randn(B * T, D) * 0.3).bfloat16()
+
+    x = qkv.float().clone().requires_grad_(True)
+    fhr, fwr = fh.clone().requires_grad_(True), fw.clone().requires_grad_(True)
+    q, k, v = [t.reshape(B, T, H, d) for t in x.split(D, dim=1)]
+    qr = ref_formula(q, pos[None].expand(B, T, 2), fhr, fwr).transpose(1, 2)
+    kr = ref_formula(k, pos[None].expand(B, T, 2), fhr, fwr).transpose(1, 2)
+    o_ref = torch.nn.functional.scaled_dot_product_attention(qr, kr, v.transpose(1, 2)).transpose(1, 2).reshape(B * T, D)
+    o_ref.backward(do.float())
+
+    xd = qkv.cuda().requires_grad_(True)
+    fhd, fwd = fh.cuda().requires_grad_(True), fw.cuda().requires_grad_(True)
+    o = ops.rope_attention(xd, pos.cuda().float().contiguous(), fhd, fwd, B, T, H, d)
+    o.backward(do.cuda())
+
+    def rel(a, b):
+        a, b = a.float().cpu(), b.float().cpu()
+        return ((a - b).norm() / b.norm()).item()
+
+    assert rel(o, o_ref) < 2e-2, rel(o, o_ref)
+    assert rel(xd.grad, x.grad) < 4e-2, rel(xd.grad, x.grad)
+    assert rel(fhd.grad, fhr.grad) < 6e-2 and rel(fwd.grad, fwr.grad) < 6e-2, (rel(fhd.grad, fhr.grad), rel(fwd.grad, fwr.grad))

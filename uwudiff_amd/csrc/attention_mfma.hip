@@ -51,7 +51,31 @@ struct MArgs {
   const float* kbias;  // optional additive score bias per key, fp32 [B, Tk] (same for every head and query)
   int B, T, Tk, H, ldq, ldk, ldv, ldo;  // T = queries, Tk = keys (== T for self-attention)
   float scale;
+  // ROPE variants: per-(token, head, element) factors of the reference's axial RoPE (y = x * m, rope.hip), fp32 [T, ldt]
+  // with the head's DH columns at hd * DH; q and k are multiplied while they are staged (both stay un-rotated in HBM)
+  const float* rope;
+  int ldt;
 };
+
+__device__ __forceinline__ uint4 rope8(uint4 v, const float* __restrict__ t) {
+  const bf16x8 b = *reinterpret_cast<const bf16x8*>(&v);
+  const f32x4 t0 = load4(t), t1 = load4(t + 4);
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    o[j] = (bf16_t)((float)b[j] * t0[j]);
+    o[4 + j] = (bf16_t)((float)b[4 + j] * t1[j]);
+  }
+  return *reinterpret_cast<const uint4*>(&o);
+}
+__device__ __forceinline__ uint2 rope4(uint2 v, const float* __restrict__ t) {
+  const bf16x4 b = *reinterpret_cast<const bf16x4*>(&v);
+  const f32x4 t0 = load4(t);
+  bf16x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = (bf16_t)((float)b[j] * t0[j]);
+  return *reinterpret_cast<const uint2*>(&o);
+}
 
 // Row-major staging of a [64 rows][64 bf16] tile: `nthr` threads, 16 B per lane, swizzled image.
 // Transposed staging of the same tile into a [64 cols][64 rows-permuted] image: 256 threads, each 4 rows x 4 cols.
@@ -60,13 +84,15 @@ struct TStage {
   // rows past `nrows` are clamped to the last one (cross-attention key tiles: their scores are masked)
   // columns at or past `ncols` (head dims that do not fill the 64-wide block) read as zero
   __device__ __forceinline__ void load(const bf16_t* __restrict__ base, int ld, int row0, int t256,
-                                       int nrows = 0x7fffffff, int ncols = 64) {
+                                       int nrows = 0x7fffffff, int ncols = 64, const float* __restrict__ tab = nullptr,
+                                       int tld = 0) {
     const int cg = t256 & 15, rq = t256 >> 4;  // cols 4cg..4cg+3, rows 4rq..4rq+3
 #pragma unroll
     for (int kr = 0; kr < 4; ++kr) {
       int row = row0 + 4 * rq + kr;
       if (row >= nrows) row = nrows - 1;
       r[kr] = (4 * cg < ncols) ? *reinterpret_cast<const uint2*>(base + (int64_t)row * ld + 4 * cg) : uint2{0u, 0u};
+      if (tab) r[kr] = rope4(r[kr], tab + (int64_t)row * tld + 4 * cg);
     }
   }
   __device__ __forceinline__ void store(char* __restrict__ lds, int t256) const {
@@ -102,7 +128,7 @@ __device__ __forceinline__ uint4 load16_or_zero(const bf16_t* p, bool ok) {
 }
 extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
 
-template <bool BIAS, int DH>
+template <bool BIAS, int DH, bool ROPE = false>
 __global__ void __launch_bounds__(256, 2) attn_fwd_mfma(const MArgs a) {
   using G = HeadGeom<DH>;
   constexpr int NB = G::NB, NKS = G::NKS, NDT = G::NDT;
@@ -133,8 +159,10 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_mfma(const MArgs a) {
   uint4 qf[NKS];
   if (active) {
 #pragma unroll
-    for (int s = 0; s < NKS; ++s)
+    for (int s = 0; s < NKS; ++s) {
       qf[s] = load16_or_zero(qb + (int64_t)(q0 + r) * a.ldq + 16 * s + 8 * h, 16 * s + 8 * h < DH);
+      if constexpr (ROPE) qf[s] = rope8(qf[s], a.rope + (int64_t)(q0 + r) * a.ldt + hd * DH + 16 * s + 8 * h);
+    }
   }
   f32x16 o[NDT];
 #pragma unroll
@@ -154,6 +182,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_mfma(const MArgs a) {
         if (row >= a.Tk) row = a.Tk - 1;  // keys past Tk: clamped, masked below
         const int col = 64 * blk + 8 * (tid & 7);
         kreg[blk][p] = load16_or_zero(kb + (int64_t)row * a.ldk + col, col < DH);
+        if constexpr (ROPE) kreg[blk][p] = rope8(kreg[blk][p], a.rope + (int64_t)row * a.ldt + hd * DH + col);
       }
       vreg[blk].load(vb + 64 * blk, a.ldv, k0, tid, a.Tk, DH - 64 * blk);
     }
@@ -283,9 +312,10 @@ __device__ __forceinline__ int off512(int row, int chunk) { return row * 512 + (
 // only dK / dV for its keys (no dS image, no K^T image: 65 KB of LDS, two workgroups per CU); dQ comes from
 // attn_bwd_dq_mfma.  The key blocks of a head sit next to each other in an XCD-aware 1-D grid (they read the same Q / dO).
 // BIAS (key-block variant only): the lane's key bias / scale is the initial value of the S accumulator.
-template <bool DQ, bool BIAS, int DH>
+template <bool DQ, bool BIAS, int DH, bool ROPE = false>
 __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
   static_assert(!(DQ && BIAS), "a key bias runs through the key-block variant");
+  static_assert(!ROPE || (DQ && DH == 64), "the RoPE variant is the one-kernel head-dim-64 case");
   static_assert(!DQ || DH == 64, "the one-kernel variant is the head-dim-64 case");
   using G = HeadGeom<DH>;
   constexpr int NB = G::NB, NKS = G::NKS, NDT = G::NDT;
@@ -323,7 +353,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
   for (int kt64 = tid >> 8; kt64 * 64 < a.T; kt64 += 2) {
     TStage ks;
     const int t256 = tid & 255;
-    ks.load(kb, a.ldk, kt64 * 64, t256);
+    ks.load(kb, a.ldk, kt64 * 64, t256, 0x7fffffff, 64, ROPE ? a.rope + hd * DH : nullptr, a.ldt);
     const int cg = t256 & 15, rq = t256 >> 4;
     const int key = kt64 * 64 + 4 * rq;
     const unsigned* w0 = reinterpret_cast<const unsigned*>(&ks.r[0]);
@@ -348,6 +378,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
 #pragma unroll
     for (int s = 0; s < NKS; ++s) {
       kf[s] = load16_or_zero(kb + (int64_t)krow * a.ldk + 16 * s + 8 * h, 16 * s + 8 * h < DH);
+      if constexpr (ROPE) kf[s] = rope8(kf[s], a.rope + (int64_t)krow * a.ldt + hd * DH + 16 * s + 8 * h);
       vf[s] = load16_or_zero(vb + (int64_t)krow * a.ldv + 16 * s + 8 * h, 16 * s + 8 * h < DH);
     }
   }
@@ -372,9 +403,11 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
     for (int blk = 0; blk < NB; ++blk) {
       const int col = 64 * blk + 8 * ch;
       qreg[blk] = load16_or_zero(qb + (int64_t)(q0 + row) * a.ldq + col, col < DH);
+      if constexpr (ROPE) qreg[blk] = rope8(qreg[blk], a.rope + (int64_t)(q0 + row) * a.ldt + hd * DH + col);
       greg[blk] = load16_or_zero(gb + (int64_t)(q0 + row) * a.ldo + col, col < DH);
       oreg[blk] = load16_or_zero(ob + (int64_t)(q0 + row) * a.ldo + col, col < DH);
-      if (tid < 256) treg[blk].load(qb + 64 * blk, a.ldq, q0, tid, 0x7fffffff, DH - 64 * blk);
+      if (tid < 256) treg[blk].load(qb + 64 * blk, a.ldq, q0, tid, 0x7fffffff, DH - 64 * blk,
+                                    ROPE ? a.rope + hd * DH + 64 * blk : nullptr, a.ldt);
       else treg[blk].load(gb + 64 * blk, a.ldo, q0, tid - 256, 0x7fffffff, DH - 64 * blk);
     }
     if (tid < 64) lreg = -lseb[q0 + tid] * inv_scale;  // row constant of S, in units of the raw dot product
@@ -763,6 +796,55 @@ void launch_bwd(const MArgs& a, hipStream_t st) {
 }
 
 }  // namespace
+
+// Self-attention with the axial-RoPE factors folded into the q / k staging: head dim 64, bf16,
+// T == Tk <= 256 (a multiple of 64) -- the DiT shapes.  The backward returns the gradients wrt the ROTATED q', k';
+// uwu_axial_rope_bwd turns them into dq, dk and the log-frequency gradients.
+extern "C" int uwu_attention_rope_fwd(const void* q, const void* k, const void* v, const float* rope_tab, void* o, float* lse,
+                                      int B, int T, int H, int d, int ldq, int ldk, int ldv, int ldo, int ldt, float scale,
+                                      int dtype, void* stream) {
+  UWU_CHECK_ARG(q && k && v && rope_tab && o && lse, "attention_rope_fwd: null pointer");
+  UWU_CHECK_ARG(dtype == UWU_BF16 && d == 64 && T % 64 == 0 && T >= 64 && T <= 256 && B > 0 && H > 0 && scale > 0.f,
+                "attention_rope_fwd: bf16, head dim 64, T a multiple of 64 up to 256 (got d=%d T=%d)", d, T);
+  UWU_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && ldt % 4 == 0 && ldt >= H * d &&
+                    (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)rope_tab) & 15) == 0,
+                "attention_rope_fwd: misaligned tensor / leading dimension");
+  MArgs a{};
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)o; a.lse = lse;
+  a.B = B; a.T = T; a.Tk = T; a.H = H; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.scale = scale;
+  a.rope = rope_tab; a.ldt = ldt;
+  UwuProfScope prof(stream);
+  hipLaunchKernelGGL((attn_fwd_mfma<false, 64, true>), dim3(((T + 127) / 128) * B * H), dim3(256), 0, (hipStream_t)stream, a);
+  prof.done(UWU_PROF_ATTN_FWD, 0, 4.0 * B * H * T * T * d, 2.0 * B * H * d * 4.0 * T);
+  UWU_LAUNCH_CHECK("attention_rope_fwd");
+  return UWU_OK;
+}
+
+extern "C" int uwu_attention_rope_bwd(const void* q, const void* k, const void* v, const float* rope_tab, const void* o,
+                                      const void* dO, const float* lse, void* dq, void* dk, void* dv, int B, int T, int H,
+                                      int d, int ldq, int ldk, int ldv, int ldo, int ldt, float scale, int dtype, void* stream) {
+  UWU_CHECK_ARG(q && k && v && rope_tab && o && dO && lse && dq && dk && dv, "attention_rope_bwd: null pointer");
+  UWU_CHECK_ARG(dtype == UWU_BF16 && d == 64 && T % 64 == 0 && T >= 64 && T <= 256 && B > 0 && H > 0 && scale > 0.f,
+                "attention_rope_bwd: bf16, head dim 64, T a multiple of 64 up to 256 (got d=%d T=%d)", d, T);
+  UWU_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && ldt % 4 == 0 && ldt >= H * d &&
+                    (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)dO | (uintptr_t)dq | (uintptr_t)dk |
+                      (uintptr_t)dv | (uintptr_t)rope_tab) & 15) == 0,
+                "attention_rope_bwd: misaligned tensor / leading dimension");
+  MArgs a{};
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o;
+  a.dO = (const bf16_t*)dO; a.lse = const_cast<float*>(lse);
+  a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
+  a.B = B; a.T = T; a.Tk = T; a.H = H; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.scale = scale;
+  a.rope = rope_tab; a.ldt = ldt;
+  static bool once = false;
+  if (!once) allow_lds(attn_bwd_mfma<true, false, 64, true>, BWD_LDS);
+  once = true;
+  UwuProfScope prof(stream);
+  hipLaunchKernelGGL((attn_bwd_mfma<true, false, 64, true>), dim3(B * H), dim3(512), BWD_LDS, (hipStream_t)stream, a);
+  prof.done(UWU_PROF_ATTN_BWD, 0, 10.0 * B * H * T * T * d, 2.0 * B * H * d * 8.0 * T);
+  UWU_LAUNCH_CHECK("attention_rope_bwd");
+  return UWU_OK;
+}
 
 int uwu_attn_mfma_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* kbias, int B,
                       int T, int Tk, int H, int d, int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t st) {

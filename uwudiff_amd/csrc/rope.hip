@@ -48,7 +48,36 @@ __global__ void __launch_bounds__(256) axial_rope_kernel(const T* __restrict__ x
   }
 }
 
+// m[t, h*d + e]: the factor y = x * m of the forward above, for shared positions pos[T, 2] -- the table the attention
+// kernels multiply q / k by while staging them (uwu_attention_rope_fwd / _bwd)
+__global__ void __launch_bounds__(256) axial_rope_table_kernel(const float* __restrict__ pos, const float* __restrict__ fh,
+                                                               const float* __restrict__ fw, float* __restrict__ tab, int T,
+                                                               int H, int d, int ldt) {
+  const int hp = d / 2, q4 = d / 4;
+  const int total = T * H * hp;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    const int i = idx % hp, r2 = idx / hp, h = r2 % H, t = r2 / H;
+    const bool wax = i >= q4;
+    const int fi = wax ? i - q4 : i;
+    const float th = pos[2 * t + (wax ? 1 : 0)] * __expf((wax ? fw : fh)[h * q4 + fi]);
+    float sn, cs;
+    __sincosf(th, &sn, &cs);
+    float* o = tab + (int64_t)t * ldt + h * d + 2 * i;
+    o[0] = cs - sn;
+    o[1] = cs + sn;
+  }
+}
+
 }  // namespace
+
+extern "C" int uwu_axial_rope_table(const float* pos, const float* fh, const float* fw, float* tab, int T, int H, int d,
+                                    int ldt, void* stream) {
+  UWU_CHECK_ARG(pos && fh && fw && tab && T > 0 && H > 0 && d > 0 && d % 4 == 0 && ldt >= H * d, "axial_rope_table: bad args");
+  hipLaunchKernelGGL(axial_rope_table_kernel, dim3(ew_grid((int64_t)T * H * (d / 2), 256)), dim3(256), 0, (hipStream_t)stream,
+                     pos, fh, fw, tab, T, H, d, ldt);
+  UWU_LAUNCH_CHECK("axial_rope_table");
+  return UWU_OK;
+}
 
 extern "C" int uwu_axial_rope_fwd(const void* x, const float* pos, const float* fh, const float* fw, void* y,
                                   int64_t rows, int H, int d, int ldx, int dtype, void* stream) {

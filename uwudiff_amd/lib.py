@@ -79,6 +79,9 @@ _SIGS = {
     "uwu_attention_bias_bwd": (c_int, [P] * 11 + [c_int] * 9 + [c_float, c_int, P]),
     "uwu_axial_rope_fwd": (c_int, [P, P, P, P, P, c_int64, c_int, c_int, c_int, c_int, P]),
     "uwu_axial_rope_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int64, c_int, c_int, c_int, c_int, P]),
+    "uwu_axial_rope_table": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "uwu_attention_rope_fwd": (c_int, [P] * 6 + [c_int] * 9 + [c_float, c_int, P]),
+    "uwu_attention_rope_bwd": (c_int, [P] * 10 + [c_int] * 9 + [c_float, c_int, P]),
     "uwu_timestep_embedding": (c_int, [P, c_int, c_int, c_float, P, c_int, P]),
     "uwu_silu_fwd": (c_int, [P, P, c_int64, c_int, P]),
     "uwu_silu_bwd": (c_int, [P, P, P, c_int64, c_int, P]),

@@ -301,3 +301,53 @@ def gemm_fp8(a8, b8, scale_a, scale_b, *, fmt_a=FP8_E4M3, bias=None, aux=None, e
            b8.stride(0), out.stride(0), aux.stride(0) if aux is not None else 0, fmt_a, epilogue, L.ptr(scale_a),
            L.ptr(scale_b), L.ptr(scratch), sbytes, L.stream())
     return (out, out2) if out2 is not None and epilogue == L.EPI_BIAS_GELU else out
+
+
+# ---------------------------------------------------------------------------------------------------- RoPE in attention
+def axial_rope_table(pos, fh, fw, H, d):
+    """Factor table m [T, H*d] (fp32) of the reference's axial RoPE for shared positions pos [T, 2]."""
+    T = pos.shape[0]
+    tab = torch.empty(T, H * d, device=pos.device, dtype=torch.float32)
+    L.call("uwu_axial_rope_table", L.ptr(pos), L.ptr(fh), L.ptr(fw), L.ptr(tab), T, H, d, H * d, L.stream())
+    return tab
+
+
+class _RopeAttentionFn(torch.autograd.Function):
+    """o = SDPA(rope(q), rope(k), v) with the rotation applied inside the attention kernels' q / k staging."""
+
+    @staticmethod
+    def forward(ctx, qkv, pos, fh, fw, B, T, H, d):
+        D = H * d
+        tab = axial_rope_table(pos, fh, fw, H, d)
+        o = torch.empty(B * T, D, device=qkv.device, dtype=qkv.dtype)
+        lse = torch.empty(B, H, T, device=qkv.device, dtype=torch.float32)
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+        L.call("uwu_attention_rope_fwd", _p(q), _p(k), _p(v), L.ptr(tab), L.ptr(o), L.ptr(lse), B, T, H, d, qkv.stride(0),
+               qkv.stride(0), qkv.stride(0), D, D, d ** -0.5, L.dt(qkv), L.stream())
+        ctx.save_for_backward(qkv, pos, fh, fw, tab, o, lse)
+        ctx.meta = (B, T, H, d)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, pos, fh, fw, tab, o, lse = ctx.saved_tensors
+        B, T, H, d = ctx.meta
+        D = H * d
+        do = do.contiguous()
+        dqkv = torch.empty_like(qkv)
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+        dq, dk, dv = dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:]
+        L.call("uwu_attention_rope_bwd", _p(q), _p(k), _p(v), L.ptr(tab), L.ptr(o), L.ptr(do), L.ptr(lse), _p(dq), _p(dk),
+               _p(dv), B, T, H, d, qkv.stride(0), qkv.stride(0), qkv.stride(0), D, D, d ** -0.5, L.dt(qkv), L.stream())
+        # dq', dk' (wrt the rotated operands) -> dq, dk in place, log-frequency gradients accumulated
+        dfh, dfw = torch.zeros_like(fh), torch.zeros_like(fw)
+        posb = pos.repeat(B, 1).contiguous()  # the standalone kernel takes one position per row
+        for x, dx in ((q, dq), (k, dk)):
+            L.call("uwu_axial_rope_bwd", _p(x), _p(dx), L.ptr(posb), L.ptr(fh), L.ptr(fw), _p(dx), L.ptr(dfh), L.ptr(dfw),
+                   B * T, H, d, qkv.stride(0), L.dt(qkv), L.stream())
+        return dqkv, None, dfh, dfw, None, None, None, None
+
+
+def rope_attention(qkv, pos, fh, fw, B, T, H, d):
+    """qkv: packed projection [B*T, 3*H*d] (bf16); pos [T, 2] fp32 (shared by the batch); fh / fw [H, d/4] log-frequencies."""
+    return _RopeAttentionFn.apply(qkv, pos, fh, fw, B, T, H, d)
