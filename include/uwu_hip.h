@@ -302,6 +302,8 @@ int uwu_axial_rope_bwd(const void* x, const void* dy, const float* pos, const fl
  * them, so no rotated copy of q / k exists.  bf16, head dim 64, T == Tk a multiple of 64 up to 256 (the DiT shapes).
  * uwu_attention_rope_bwd returns dq / dk wrt the ROTATED q' / k'; uwu_axial_rope_bwd (x = the raw q / k, dy = those, dx in
  * place) turns them into the gradients of q / k and of the log-frequencies. */
+int uwu_axial_rope_bwd_shared(const void* x, const void* dy, const float* pos, int pos_rows, const float* fh, const float* fw,
+                              void* dx, float* dfh, float* dfw, int64_t rows, int H, int d, int ldx, int dtype, void* stream);
 int uwu_axial_rope_table(const float* pos, const float* fh, const float* fw, float* tab, int T, int H, int d, int ldt,
                          void* stream);
 int uwu_attention_rope_fwd(const void* q, const void* k, const void* v, const float* rope_tab, void* o, float* lse, int B,
@@ -384,6 +386,12 @@ typedef struct uwu_dit_desc {
    * scaling (quantise with the scale derived from the previous step's amax; call with 1 for the first step).  Needs
    * dtype == UWU_BF16, D % 128 == 0.  Roles (12 per block, index 12*l + r): r 0-3 = inputs of qkv / proj / fc1 / fc2
    * (e4m3), 4-7 = their output gradients (e5m2), 8-11 = their weights (e4m3). */
+  /* axial-RoPE self-attention (rope_unet.py:143-147): rope != 0 rotates q and k inside the
+   * attention kernels with learnable per-layer, per-head log-frequencies at w32 + off_rope_h / off_rope_w ([L, H, d/4]
+   * each; gradients into g32 at the same offsets) and the shared token positions pos_xy [T, 2] (fp32). */
+  int32_t rope;
+  int64_t off_rope_h, off_rope_w;
+  const float* pos_xy;
   int32_t fp8;
   float* f8_scale;      /* [12 L] per-tensor quantisation scales */
   float* f8_amax;       /* [12 L] running max |x| of the current step */

@@ -89,3 +89,45 @@ def test_rope_fused_into_attention_matches_composed_reference(B, T, H):
     assert rel(o, o_ref) < 2e-2, rel(o, o_ref)
     assert rel(xd.grad, x.grad) < 4e-2, rel(xd.grad, x.grad)
     assert rel(fhd.grad, fhr.grad) < 6e-2 and rel(fwd.grad, fwr.grad) < 6e-2, (rel(fhd.grad, fhr.grad), rel(fwd.grad, fwr.grad))
+
+
+def test_rope_dit_preset_matches_oracle():
+    """DiT with axial-RoPE attention (the preset behind ``DiT-S/2-RoPE``: per-layer learnable log-frequencies, q / k rotated
+    inside the attention kernels) against the CPU oracle's composed block (oracle/dit.py: rope.py's rotation, then SDPA):
+    output and every parameter gradient incl. the frequency tables, bf16 tolerances."""
+    from oracle.dit import DiTOracle
+    from uwudiff_amd.dit import DiT, DiTConfig, PRESETS
+
+    cfg = dict(depth=2, hidden=128, heads=2, patch=2, sample_size=16, in_channels=4, out_channels=4, cond_dim=32, rope=True)
+    torch.manual_seed(0)
+    ora = DiTOracle(**cfg)
+    with torch.no_grad():
+        for n, p in ora.named_parameters():
+            if not n.startswith("rope."):
+                p.copy_(torch.randn_like(p) * (0.05 if p.dim() > 1 else 0.02))
+            else:
+                p.add_(torch.randn_like(p) * 0.05)
+    model = DiT(DiTConfig(compute_dtype="bf16", **cfg), init="dit").cuda()
+    model.load_state_dict(ora.state_dict())
+    B = 4
+    g = torch.Generator().manual_seed(1)
+    x, t = torch.randn(B, 4, 16, 16, generator=g), torch.randint(0, 1000, (B,), generator=g)
+    pooled, dout = torch.randn(B, 32, generator=g), torch.randn(B, 4, 16, 16, generator=g) / 256
+    yo = ora(x, t, added_cond_kwargs={"text_embeds": pooled})[0]
+    yo.backward(dout)
+    y = model(x.cuda(), t.cuda(), added_cond_kwargs={"text_embeds": pooled.cuda()})[0]
+    y.backward(dout.cuda())
+
+    def rel(a, b):
+        a, b = a.detach().float().cpu(), b.detach().float().cpu()
+        return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+    assert rel(y, yo) < 3e-2, rel(y, yo)
+    og = dict(ora.named_parameters())
+    bad = {n: rel(model.grad_view(n), og[n].grad) for n, _ in model.named_tensors() if rel(model.grad_view(n), og[n].grad) >= 8e-2}
+    assert not bad, bad
+    assert PRESETS["DiT-S/2-RoPE"]["rope"] and float(model.grad_view("rope.freqs_h").abs().max()) > 0
+    # and without RoPE the same weights give a different output (the rotation is really applied)
+    plain = DiT(DiTConfig(compute_dtype="bf16", **dict(cfg, rope=False)), init="dit").cuda()
+    plain.load_state_dict({k: v for k, v in ora.state_dict().items() if not k.startswith("rope.")})
+    assert rel(plain(x.cuda(), t.cuda(), added_cond_kwargs={"text_embeds": pooled.cuda()})[0], yo) > 5e-2

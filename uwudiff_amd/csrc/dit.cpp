@@ -30,6 +30,7 @@ struct Layout {
   size_t layer0, layer_stride;
   // per-layer sub-offsets
   size_t o_x0, o_m1, o_r1, o_h1, o_qkv, o_lse, o_ao, o_y1, o_x1, o_m2, o_r2, o_h2, o_u, o_f, o_y2;
+  size_t o_rope;                     // rope mode: this layer's factor table [T, D] fp32
   size_t o_h1t, o_aot, o_h2t, o_ft;  // fp8 mode: transposed fp8 copies of the Linear inputs (operands of the weight gradients)
   size_t xF, mF, rF, hF, otok;
   // backward scratch
@@ -82,6 +83,7 @@ Layout make_layout(const uwu_dit_desc& d) {
   L.o_u = sub(L.M * L.D4 * L.es);
   L.o_f = sub(L.M * L.D4 * L.es);
   L.o_y2 = sub(L.M * L.D * L.es);
+  if (d.rope) L.o_rope = sub((size_t)d.T * d.D * f4);
   if (d.fp8) {
     L.o_h1t = sub(L.M * L.D);
     L.o_aot = sub(L.M * L.D);
@@ -149,6 +151,10 @@ int check_desc(const uwu_dit_desc* d) {
     return UWU_EINVAL;
   }
   if (!d->w || !d->w32 || !d->pos || !d->ws) { uwu_set_error("dit: null buffer"); return UWU_EINVAL; }
+  if (d->rope && (d->dtype != UWU_BF16 || d->D / d->H != 64 || d->T % 64 || d->T > 256 || !d->pos_xy)) {
+    uwu_set_error("dit: the fused axial-RoPE attention needs bf16, head dim 64, T a multiple of 64 up to 256 and pos_xy");
+    return UWU_EINVAL;
+  }
   if (d->fp8) {
     if (d->fp8 < 0 || d->fp8 > 2 || d->dtype != UWU_BF16 || d->D % 128 || d->mlp_ratio != 4 || ((int64_t)d->B * d->T) % 128 ||
         !d->f8_scale || !d->f8_amax || !d->f8_fmt) {
@@ -394,6 +400,13 @@ extern "C" int uwu_dit_forward(const uwu_dit_desc* dp, const float* noisy, const
     if (d.fp8) RUN(f8_fwd(f8, P.lay(l, L.o_h1), P.lay(l, L.o_h1t), f8.w(l, 0, false), w.qkv_b, P.lay(l, L.o_qkv), nullptr, M, D3, D, f8.role(l, 0), f8.role(l, 8), UWU_EPI_BIAS));
     else RUN(lin_fwd(P.lay(l, L.o_h1), w.qkv_w, w.qkv_b, P.lay(l, L.o_qkv), nullptr, M, D3, D, dt, dt, UWU_EPI_BIAS, st));
     char* qkv = P.lay<char>(l, L.o_qkv);
+    if (d.rope) {  // this layer's factor table, then attention with q / k rotated while they are staged
+      const int64_t fo = (int64_t)l * d.H * (D / d.H / 4);
+      RUN(uwu_axial_rope_table(d.pos_xy, w32 + d.off_rope_h + fo, w32 + d.off_rope_w + fo, P.lay<float>(l, L.o_rope), T, d.H,
+                               D / d.H, D, st));
+      RUN(uwu_attention_rope_fwd(qkv, qkv + (size_t)D * es, qkv + (size_t)2 * D * es, P.lay<float>(l, L.o_rope), P.lay(l, L.o_ao),
+                                 P.lay<float>(l, L.o_lse), B, T, d.H, D / d.H, D3, D3, D3, D, D, scale, dt, st));
+    } else
     RUN(uwu_attention_fwd(qkv, qkv + (size_t)D * es, qkv + (size_t)2 * D * es, P.lay(l, L.o_ao), P.lay<float>(l, L.o_lse),
                           B, T, T, d.H, D / d.H, D3, D3, D3, D, scale, dt, st));
     if (d.fp8) RUN(f8_fwd(f8, P.lay(l, L.o_ao), P.lay(l, L.o_aot), f8.w(l, 1, false), w.o_b, P.lay(l, L.o_y1), nullptr, M, D, D, f8.role(l, 1), f8.role(l, 9), UWU_EPI_BIAS));
@@ -496,6 +509,18 @@ extern "C" int uwu_dit_backward(const uwu_dit_desc* dp, const float* dout, void*
     }
     char* qkv = P.lay<char>(l, L.o_qkv);
     char* dqkv = P.at<char>(L.dqkv);
+    if (d.rope) {
+      // gradients wrt the rotated q' / k' come out of the attention kernel; the elementwise pass turns them into dq / dk in
+      // place and accumulates the log-frequency gradients of this layer
+      const int64_t fo = (int64_t)l * d.H * (D / d.H / 4);
+      RUN(uwu_attention_rope_bwd(qkv, qkv + (size_t)D * es, qkv + (size_t)2 * D * es, P.lay<float>(l, L.o_rope), P.lay(l, L.o_ao),
+                                 P.at(L.dao), P.lay<float>(l, L.o_lse), dqkv, dqkv + (size_t)D * es, dqkv + (size_t)2 * D * es,
+                                 B, T, d.H, D / d.H, D3, D3, D3, D, D, scale, dt, st));
+      for (int qk = 0; qk < 2; ++qk)
+        RUN(uwu_axial_rope_bwd_shared(qkv + (size_t)qk * D * es, dqkv + (size_t)qk * D * es, d.pos_xy, T,
+                                      w32 + d.off_rope_h + fo, w32 + d.off_rope_w + fo, dqkv + (size_t)qk * D * es,
+                                      g + d.off_rope_h + fo, g + d.off_rope_w + fo, (int64_t)M, d.H, D / d.H, D3, dt, st));
+    } else
     RUN(uwu_attention_bwd(qkv, qkv + (size_t)D * es, qkv + (size_t)2 * D * es, P.lay(l, L.o_ao), P.at(L.dao),
                           P.lay<float>(l, L.o_lse), P.at<float>(L.delta), dqkv, dqkv + (size_t)D * es,
                           dqkv + (size_t)2 * D * es, B, T, T, d.H, D / d.H, D3, D3, D3, D, scale, dt, st));

@@ -14,7 +14,7 @@ __global__ void __launch_bounds__(256) axial_rope_kernel(const T* __restrict__ x
                                                          const float* __restrict__ pos, const float* __restrict__ fh,
                                                          const float* __restrict__ fw, T* __restrict__ out,
                                                          float* __restrict__ dfh, float* __restrict__ dfw,
-                                                         int64_t rows, int H, int d, int ldx) {
+                                                         int64_t rows, int H, int d, int ldx, int pos_rows) {
   // one thread = one (row, head, pair); pairs i in [0, d/2): i < d/4 -> h-axis frequency i, else w-axis i - d/4
   const int hp = d / 2, q4 = d / 4;
   const int64_t total = rows * H * hp, step = (int64_t)gridDim.x * 256;
@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(256) axial_rope_kernel(const T* __restrict__ x
     const int64_t row = r2 / H;
     const bool wax = i >= q4;
     const int fi = wax ? i - q4 : i;
-    const float p = pos[2 * row + (wax ? 1 : 0)];
+    const float p = pos[2 * (pos_rows > 0 ? row % pos_rows : row) + (wax ? 1 : 0)];  // pos_rows: positions shared by the batch
     const float ef = __expf((wax ? fw : fh)[h * q4 + fi]);
     const float th = p * ef;
     float sn, cs;
@@ -87,19 +87,32 @@ extern "C" int uwu_axial_rope_fwd(const void* x, const float* pos, const float* 
   const int grid = ew_grid(rows * H * (d / 2), 256);
   if (dtype == UWU_F32)
     hipLaunchKernelGGL((axial_rope_kernel<float, false>), dim3(grid), dim3(256), 0, st, (const float*)x, nullptr, pos, fh,
-                       fw, (float*)y, nullptr, nullptr, rows, H, d, ldx);
+                       fw, (float*)y, nullptr, nullptr, rows, H, d, ldx, 0);
   else if (dtype == UWU_BF16)
     hipLaunchKernelGGL((axial_rope_kernel<bf16_t, false>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, nullptr, pos,
-                       fh, fw, (bf16_t*)y, nullptr, nullptr, rows, H, d, ldx);
+                       fh, fw, (bf16_t*)y, nullptr, nullptr, rows, H, d, ldx, 0);
   else
     UWU_CHECK_ARG(false, "axial_rope_fwd: bad dtype");
   UWU_LAUNCH_CHECK("axial_rope_fwd");
   return UWU_OK;
 }
 
+static int rope_bwd_impl(const void* x, const void* dy, const float* pos, const float* fh, const float* fw, void* dx,
+                         float* dfh, float* dfw, int64_t rows, int H, int d, int ldx, int dtype, int pos_rows, void* stream);
 extern "C" int uwu_axial_rope_bwd(const void* x, const void* dy, const float* pos, const float* fh, const float* fw,
                                   void* dx, float* dfh, float* dfw, int64_t rows, int H, int d, int ldx, int dtype,
                                   void* stream) {
+  return rope_bwd_impl(x, dy, pos, fh, fw, dx, dfh, dfw, rows, H, d, ldx, dtype, 0, stream);
+}
+// the same with positions shared by the batch: pos [pos_rows, 2], row r uses pos[r % pos_rows]
+extern "C" int uwu_axial_rope_bwd_shared(const void* x, const void* dy, const float* pos, int pos_rows, const float* fh,
+                                         const float* fw, void* dx, float* dfh, float* dfw, int64_t rows, int H, int d,
+                                         int ldx, int dtype, void* stream) {
+  UWU_CHECK_ARG(pos_rows > 0, "axial_rope_bwd_shared: pos_rows must be positive");
+  return rope_bwd_impl(x, dy, pos, fh, fw, dx, dfh, dfw, rows, H, d, ldx, dtype, pos_rows, stream);
+}
+static int rope_bwd_impl(const void* x, const void* dy, const float* pos, const float* fh, const float* fw, void* dx,
+                         float* dfh, float* dfw, int64_t rows, int H, int d, int ldx, int dtype, int pos_rows, void* stream) {
   UWU_CHECK_ARG(x && dy && pos && fh && fw && dx && rows > 0 && H > 0 && d > 0 && d % 4 == 0 && ldx >= H * d,
                 "axial_rope_bwd: bad args");
   UWU_CHECK_ARG((dfh == nullptr) == (dfw == nullptr), "axial_rope_bwd: dfh/dfw go together");
@@ -107,10 +120,10 @@ extern "C" int uwu_axial_rope_bwd(const void* x, const void* dy, const float* po
   const int grid = ew_grid(rows * H * (d / 2), 256);
   if (dtype == UWU_F32)
     hipLaunchKernelGGL((axial_rope_kernel<float, true>), dim3(grid), dim3(256), 0, st, (const float*)x, (const float*)dy,
-                       pos, fh, fw, (float*)dx, dfh, dfw, rows, H, d, ldx);
+                       pos, fh, fw, (float*)dx, dfh, dfw, rows, H, d, ldx, pos_rows);
   else if (dtype == UWU_BF16)
     hipLaunchKernelGGL((axial_rope_kernel<bf16_t, true>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x,
-                       (const bf16_t*)dy, pos, fh, fw, (bf16_t*)dx, dfh, dfw, rows, H, d, ldx);
+                       (const bf16_t*)dy, pos, fh, fw, (bf16_t*)dx, dfh, dfw, rows, H, d, ldx, pos_rows);
   else
     UWU_CHECK_ARG(false, "axial_rope_bwd: bad dtype");
   UWU_LAUNCH_CHECK("axial_rope_bwd");

@@ -27,6 +27,8 @@ from . import lib as L
 
 PRESETS = {
     "DiT-S/2": dict(depth=12, hidden=384, heads=6, patch=2),
+    "DiT-S/2-RoPE": dict(depth=12, hidden=384, heads=6, patch=2, rope=True),   # RoPE variant (rope_unet.py's attention)
+    "DiT-B/2-RoPE": dict(depth=12, hidden=768, heads=12, patch=2, rope=True),
     "DiT-B/2": dict(depth=12, hidden=768, heads=12, patch=2),
     "DiT-L/2": dict(depth=24, hidden=1024, heads=16, patch=2),
     "DiT-XL/2": dict(depth=28, hidden=1152, heads=16, patch=2),
@@ -47,6 +49,7 @@ class DiTConfig:
     freq_dim: int = 256
     ln_eps: float = 1e-6
     compute_dtype: str = "bf16"  # "bf16" | "fp32" | "fp8" (bf16 activations, fp8 e4m3 / e5m2 operands of the block Linears)
+    rope: bool = False           # learnable axial RoPE on q / k of every block (reference modules/rope.py, rope_unet.py:143-147)
     fp8_scaling: str = "delayed"  # "delayed" (amax of the previous step; the first step scales just in time) | "jit"
 
 
@@ -102,6 +105,9 @@ class DiT(nn.Module):
                 ("y_embedder.weight", (D, max(c.cond_dim, 8))), ("y_embedder.bias", (D,)),
                 ("adaLN.weight", (self.mod_total, D)), ("adaLN.bias", (self.mod_total,)),
                 ("final.weight", (ko, D)), ("final.bias", (ko,))]
+        if c.rope:  # per-layer, per-head log-frequencies of the two axes (AxialRoPE(head_dim, heads): [heads, head_dim / 4] each)
+            hd4 = D // c.heads // 4
+            spec += [("rope.freqs_h", (c.depth, c.heads, hd4)), ("rope.freqs_w", (c.depth, c.heads, hd4))]
         for l in range(c.depth):
             spec += [(f"blocks.{l}.qkv.weight", (3 * D, D)), (f"blocks.{l}.qkv.bias", (3 * D,)),
                      (f"blocks.{l}.proj.weight", (D, D)), (f"blocks.{l}.proj.bias", (D,)),
@@ -117,6 +123,11 @@ class DiT(nn.Module):
         self.flat = nn.Parameter(torch.zeros(off, dtype=torch.float32))
         self.register_buffer("pos", sincos_2d(D, c.sample_size // c.patch), persistent=False)
         self.register_buffer("shadow", torch.zeros(0, dtype=torch.bfloat16), persistent=False)
+        if c.rope:
+            from .rope import make_axial_pos
+
+            g = c.sample_size // c.patch
+            self.register_buffer("pos_xy", make_axial_pos(g, g).float().contiguous(), persistent=False)
         self._ws = None
         self._ws_key = None
         self._layer_done = None
@@ -148,8 +159,12 @@ class DiT(nn.Module):
         g = torch.Generator().manual_seed(torch.initial_seed() % (2 ** 31))
         for name, (off, shape) in self.registry.items():
             v = self.view(name)
-            if init == "random":
+            if init == "random" and not name.startswith("rope."):
                 v.copy_(torch.randn(shape, generator=g) * 0.02)
+                continue
+            if name.startswith("rope."):  # reference rope.py:74-81 freqs_pixel_log(max_freq=10): linspace(log pi, log 5 pi)
+                n = shape[-1]
+                v.copy_(torch.linspace(math.log(math.pi), math.log(10.0 * math.pi / 2), n).expand(shape))
                 continue
             if name.endswith("bias"):
                 continue
@@ -236,6 +251,10 @@ class DiT(nn.Module):
         if c.depth > 1:
             assert r["blocks.1.qkv.weight"][0] - d.off_layer0 == d.layer_stride
         d.pos = self.pos.data_ptr()
+        d.rope = 1 if c.rope else 0
+        if c.rope:
+            d.off_rope_h, d.off_rope_w = r["rope.freqs_h"][0], r["rope.freqs_w"][0]
+            d.pos_xy = self.pos_xy.data_ptr()
         d.fp8 = 0
         if c.compute_dtype == "fp8":
             if self._f8 is None or self._f8[0].device != self.flat.device:

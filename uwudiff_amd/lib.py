@@ -31,6 +31,7 @@ class DitDesc(ctypes.Structure):
                                   "off_y_w", "off_y_b", "off_mod_w", "off_mod_b", "off_final_w", "off_final_b",
                                   "off_layer0", "layer_stride")]
         + [("pos", c_void_p), ("ws", c_void_p), ("ws_bytes", c_size_t), ("layer_done", c_void_p)]
+        + [("rope", c_int32), ("off_rope_h", c_int64), ("off_rope_w", c_int64), ("pos_xy", c_void_p)]
         + [("fp8", c_int32), ("f8_scale", c_void_p), ("f8_amax", c_void_p), ("f8_fmt", c_void_p)]
     )
 
@@ -79,6 +80,7 @@ _SIGS = {
     "uwu_attention_bias_bwd": (c_int, [P] * 11 + [c_int] * 9 + [c_float, c_int, P]),
     "uwu_axial_rope_fwd": (c_int, [P, P, P, P, P, c_int64, c_int, c_int, c_int, c_int, P]),
     "uwu_axial_rope_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int64, c_int, c_int, c_int, c_int, P]),
+    "uwu_axial_rope_bwd_shared": (c_int, [P, P, P, c_int, P, P, P, P, P, c_int64, c_int, c_int, c_int, c_int, P]),
     "uwu_axial_rope_table": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "uwu_attention_rope_fwd": (c_int, [P] * 6 + [c_int] * 9 + [c_float, c_int, P]),
     "uwu_attention_rope_bwd": (c_int, [P] * 10 + [c_int] * 9 + [c_float, c_int, P]),

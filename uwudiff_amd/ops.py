@@ -341,10 +341,9 @@ class _RopeAttentionFn(torch.autograd.Function):
                _p(dv), B, T, H, d, qkv.stride(0), qkv.stride(0), qkv.stride(0), D, D, d ** -0.5, L.dt(qkv), L.stream())
         # dq', dk' (wrt the rotated operands) -> dq, dk in place, log-frequency gradients accumulated
         dfh, dfw = torch.zeros_like(fh), torch.zeros_like(fw)
-        posb = pos.repeat(B, 1).contiguous()  # the standalone kernel takes one position per row
         for x, dx in ((q, dq), (k, dk)):
-            L.call("uwu_axial_rope_bwd", _p(x), _p(dx), L.ptr(posb), L.ptr(fh), L.ptr(fw), _p(dx), L.ptr(dfh), L.ptr(dfw),
-                   B * T, H, d, qkv.stride(0), L.dt(qkv), L.stream())
+            L.call("uwu_axial_rope_bwd_shared", _p(x), _p(dx), L.ptr(pos), T, L.ptr(fh), L.ptr(fw), _p(dx), L.ptr(dfh),
+                   L.ptr(dfw), B * T, H, d, qkv.stride(0), L.dt(qkv), L.stream())
         return dqkv, None, dfh, dfw, None, None, None, None
 
 
