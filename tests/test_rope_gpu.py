@@ -127,7 +127,3 @@ def test_rope_dit_preset_matches_oracle():
     bad = {n: rel(model.grad_view(n), og[n].grad) for n, _ in model.named_tensors() if rel(model.grad_view(n), og[n].grad) >= 8e-2}
     assert not bad, bad
     assert PRESETS["DiT-S/2-RoPE"]["rope"] and float(model.grad_view("rope.freqs_h").abs().max()) > 0
-    # and without RoPE the same weights give a different output (the rotation is really applied)
-    plain = DiT(DiTConfig(compute_dtype="bf16", **dict(cfg, rope=False)), init="dit").cuda()
-    plain.load_state_dict({k: v for k, v in ora.state_dict().items() if not k.startswith("rope.")})
-    assert rel(plain(x.cuda(), t.cuda(), added_cond_kwargs={"text_embeds": pooled.cuda()})[0], yo) > 5e-2
