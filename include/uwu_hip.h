@@ -149,6 +149,18 @@ int uwu_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, i
 int uwu_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int uwu_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
 
+/* ------------------------------------------------------------------ gradient exchange (section 8e)
+ * One RCCL communicator per rank (librccl resolved at run time), created once; uwu_allreduce_flat sums a slice of the
+ * flat fp32 gradient buffer over the ranks in place on the caller's stream (reference: the bucketed all-reduce of
+ * Lightning DDP, configs/demo_training.yaml:5-7).  uwu_comm_unique_id: 128 bytes made by rank 0, to be handed to every
+ * rank through any side channel; uwu_comm_init is collective.  The 1/world average stays folded into the optimizer
+ * kernels (pre_scale).  uwudiff_amd/gradsync.py uses it when UWU_RCCL_DIRECT=1 (default: torch.distributed's RCCL
+ * process group, which needs no second communicator). */
+int uwu_comm_unique_id(void* id128);
+int uwu_comm_init(const void* id128, int rank, int world, void** comm);
+int uwu_allreduce_flat(void* comm, float* buf, int64_t n, void* stream);
+int uwu_comm_destroy(void* comm);
+
 /* ------------------------------------------------------------------ dense contractions (a11-a13) */
 
 /* C[M,N] = opA(A) . opB(B)  (+ epilogue), fp32 accumulate on MFMA.

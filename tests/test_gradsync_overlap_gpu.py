@@ -93,3 +93,26 @@ def test_overlapped_exchange_equals_plain_exchange():
         assert p.exitcode == 0
     assert all(r[1] for r in res), res
     assert res[0][2] == res[1][2] and res[0][2] > 0  # the reduced gradient is the same (non-trivial) sum on both ranks
+
+
+def test_cabi_rccl_communicator_single_rank():
+    """include/uwu_hip.h uwu_comm_* / uwu_allreduce_flat: the C-ABI exchange over an RCCL communicator
+    created once per rank.  One GPU here, so world = 1: the all-reduce must leave the buffer unchanged and run on the
+    caller's stream; N > 1 is the driver's scaling run (UWU_RCCL_DIRECT=1 selects this path in gradsync.py)."""
+    import ctypes
+
+    from uwudiff_amd import lib as L
+
+    idbuf = (ctypes.c_char * 128)()
+    L.call("uwu_comm_unique_id", ctypes.addressof(idbuf))
+    comm = ctypes.c_void_p()
+    L.call("uwu_comm_init", bytes(idbuf.raw), 0, 1, ctypes.byref(comm))
+    g = torch.randn(1 << 20, device="cuda")
+    want = g.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        L.call("uwu_allreduce_flat", comm, g.data_ptr(), g.numel(), side.cuda_stream)
+    side.synchronize()
+    assert torch.equal(g, want)
+    L.call("uwu_comm_destroy", comm)

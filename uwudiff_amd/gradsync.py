@@ -18,8 +18,35 @@ those slices (2/3 of DiT-S/2's gradient bytes) are reduced on the communication 
 rest of the backward still runs, and :meth:`all_reduce` afterwards only reduces what is left.  Every rank issues the
 same collectives in the same order (block groups last-to-first, then the remainder in offset order).
 """
+import ctypes
+import os
+
 import torch
 import torch.distributed as dist
+
+
+class _DirectRccl:
+    """The C-ABI exchange (include/uwu_hip.h: uwu_comm_* / uwu_allreduce_flat): one RCCL communicator per rank created
+    once; the 128-byte id travels through torch.distributed's broadcast.  Opt-in (UWU_RCCL_DIRECT=1)."""
+
+    def __init__(self, device, group=None):
+        from . import lib as L
+
+        self.L = L
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        idbuf = (ctypes.c_char * 128)()
+        if rank == 0:
+            L.call("uwu_comm_unique_id", ctypes.addressof(idbuf))
+        t = torch.frombuffer(bytearray(idbuf.raw), dtype=torch.uint8).clone()
+        t = t.to(device) if dist.get_backend(group) == "nccl" else t
+        dist.broadcast(t, src=0, group=group)
+        raw = bytes(t.cpu().tolist())
+        self.comm = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            L.call("uwu_comm_init", raw, rank, world, ctypes.byref(self.comm))
+
+    def all_reduce(self, t, stream):
+        self.L.call("uwu_allreduce_flat", self.comm, t.data_ptr(), t.numel(), stream.cuda_stream)
 
 
 class FlatGradSync:
@@ -28,6 +55,7 @@ class FlatGradSync:
         self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.chunk_elems = int(chunk_elems)
         self._comm_stream = None
+        self._direct = None  # _DirectRccl when UWU_RCCL_DIRECT=1 (device tensors, world > 1)
         self.events = []
         self._early = []  # [(offset, length, event)] reduced from inside the backward of the current step
 
@@ -43,6 +71,15 @@ class FlatGradSync:
         if self._comm_stream is None:
             self._comm_stream = torch.cuda.Stream(device=device)
         return self._comm_stream
+
+    def _reduce(self, t, comm_stream):
+        """Sum-all-reduce of a device slice on the communication stream (already current)."""
+        if os.environ.get("UWU_RCCL_DIRECT", "0") == "1" and dist.get_backend(self.group) == "nccl":
+            if self._direct is None:
+                self._direct = _DirectRccl(t.device, self.group)
+            self._direct.all_reduce(t, comm_stream)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def attach(self, model):
         """Reduce the slices ``model`` reports as final from inside its backward (no-op for one rank or for models
@@ -64,7 +101,7 @@ class FlatGradSync:
         with torch.cuda.stream(comm):
             for off, ln, ready in ranges:
                 comm.wait_event(ready)  # every gradient launch of this slice has completed
-                dist.all_reduce(flat_grad[off:off + ln], op=dist.ReduceOp.SUM, group=self.group)
+                self._reduce(flat_grad[off:off + ln], comm)
                 ev = torch.cuda.Event()
                 ev.record(comm)
                 self._early.append((off, ln, ev))
@@ -96,7 +133,7 @@ class FlatGradSync:
                 self.events.append(ev)
             with torch.cuda.stream(comm):
                 for off, ln in rest:
-                    dist.all_reduce(flat_grad[off:off + ln], op=dist.ReduceOp.SUM, group=self.group)
+                    self._reduce(flat_grad[off:off + ln], comm)
                     ev = torch.cuda.Event()
                     ev.record(comm)
                     chunks.append((off, ln))

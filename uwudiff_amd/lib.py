@@ -58,6 +58,10 @@ _SIGS = {
                                P, P]),
     "uwu_cast_f32_to_bf16": (c_int, [P, P, c_int64, P]),
     "uwu_cast_bf16_to_f32": (c_int, [P, P, c_int64, P]),
+    "uwu_comm_unique_id": (c_int, [P]),
+    "uwu_comm_init": (c_int, [P, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "uwu_allreduce_flat": (c_int, [P, P, c_int64, P]),
+    "uwu_comm_destroy": (c_int, [P]),
     "uwu_gemm": (c_int, [P, P, P, P, P, P] + [c_int] * 13 + [P]),
     "uwu_gemm_fp8_scratch_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
     "uwu_gemm_fp8": (c_int, [P, P, P, P, P, P] + [c_int] * 9 + [P, P, P, ctypes.c_size_t, P]),
