@@ -398,6 +398,9 @@ typedef struct uwu_dit_desc {
    * scaling (quantise with the scale derived from the previous step's amax; call with 1 for the first step).  Needs
    * dtype == UWU_BF16, D % 128 == 0.  Roles (12 per block, index 12*l + r): r 0-3 = inputs of qkv / proj / fc1 / fc2
    * (e4m3), 4-7 = their output gradients (e5m2), 8-11 = their weights (e4m3). */
+  /* optional second stream (hipStream_t) for the weight gradients of small batches (B*T <= 16384 token rows, bf16): they
+   * run beside the chain of input gradients, ordered by events; NULL = everything on the call's stream. */
+  void* side_stream;
   /* axial-RoPE self-attention (rope_unet.py:143-147): rope != 0 rotates q and k inside the
    * attention kernels with learnable per-layer, per-head log-frequencies at w32 + off_rope_h / off_rope_w ([L, H, d/4]
    * each; gradients into g32 at the same offsets) and the shared token positions pos_xy [T, 2] (fp32). */

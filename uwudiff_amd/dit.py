@@ -18,6 +18,7 @@ AdamW launch and one all-reduce per step.  Forward and backward are each a singl
 """
 import ctypes
 import math
+import os
 from dataclasses import dataclass
 
 import torch
@@ -136,6 +137,7 @@ class DiT(nn.Module):
         self._grad_groups = None
         self._fwd_gen = 0
         self._desc = None
+        self._side = None      # second HIP stream: weight gradients of small batches run beside the input-gradient chain
         self._f8 = None        # (scale, amax, fmt) device tensors of the fp8 mode, 12 roles per block
         self._f8_steps = 0     # forward passes taken in fp8 mode (the first one always scales just in time)
         self.config = type("cfg", (), dict(in_channels=c.in_channels, sample_size=c.sample_size))()
@@ -251,6 +253,11 @@ class DiT(nn.Module):
         if c.depth > 1:
             assert r["blocks.1.qkv.weight"][0] - d.off_layer0 == d.layer_stride
         d.pos = self.pos.data_ptr()
+        d.side_stream = None
+        if bf and B * self.T <= 16384 and os.environ.get("UWU_DIT_FORK", "1") != "0":
+            if self._side is None or self._side.device != self.flat.device:
+                self._side = torch.cuda.Stream(device=self.flat.device)
+            d.side_stream = self._side.cuda_stream
         d.rope = 1 if c.rope else 0
         if c.rope:
             d.off_rope_h, d.off_rope_w = r["rope.freqs_h"][0], r["rope.freqs_w"][0]

@@ -31,6 +31,7 @@ class DitDesc(ctypes.Structure):
                                   "off_y_w", "off_y_b", "off_mod_w", "off_mod_b", "off_final_w", "off_final_b",
                                   "off_layer0", "layer_stride")]
         + [("pos", c_void_p), ("ws", c_void_p), ("ws_bytes", c_size_t), ("layer_done", c_void_p)]
+        + [("side_stream", c_void_p)]
         + [("rope", c_int32), ("off_rope_h", c_int64), ("off_rope_w", c_int64), ("pos_xy", c_void_p)]
         + [("fp8", c_int32), ("f8_scale", c_void_p), ("f8_amax", c_void_p), ("f8_fmt", c_void_p)]
     )
