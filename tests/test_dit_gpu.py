@@ -146,3 +146,32 @@ def test_dit_requires_device():
     m = DiT(DiTConfig(compute_dtype="fp32", **SMALL))
     with pytest.raises(L.UwuError):
         m(torch.randn(1, 4, 16, 16), torch.tensor([1]))
+
+
+def test_dit_small_batch_forked_backward_equals_single_stream(monkeypatch):
+    """Per-GPU batch 16 (the reference YAML's): the weight gradients run on a second stream beside the input-gradient chain,
+    ordered only by events.  Gradients must equal the single-stream backward up to the order of fp32 atomic adds -- a missing
+    wait would show as a stale dY / dU / dQKV tile, i.e. errors of order one.  Repeated, because a race need not hit every time."""
+    from uwudiff_amd.dit import DiT
+
+    torch.manual_seed(5)
+    model = DiT.from_config("DiT-S/2", cond_dim=1280, init="random", compute_dtype="bf16").cuda()
+    B = 16
+    x, t = torch.randn(B, 4, 32, 32, device="cuda"), torch.randint(0, 1000, (B,), device="cuda").float()
+    c, w = torch.randn(B, 1280, device="cuda"), torch.randn(B, 4, 32, 32, device="cuda") / 4096
+
+    def grads():
+        model.flat.grad = torch.zeros_like(model.flat.data)
+        out = model(x, t, added_cond_kwargs={"text_embeds": c})[0]
+        (out * w).sum().backward()
+        torch.cuda.synchronize()
+        return model.flat.grad.clone()
+
+    monkeypatch.setenv("UWU_DIT_FORK", "0")
+    ref = grads()
+    monkeypatch.setenv("UWU_DIT_FORK", "1")
+    for _ in range(6):
+        g = grads()
+        l2, mx = rel(g, ref)
+        assert l2 < 1e-4 and mx < 1e-3, (l2, mx)
+    assert model._side is not None

@@ -315,9 +315,11 @@ def test_gemm_tr_random(monkeypatch):
 @pytest.mark.parametrize("M,N,K", [(1536, 384, 65536), (1152, 384, 8192), (384, 1536, 4096), (200, 264, 2048),
                                    (384, 384, 6144), (200, 384, 4096), (384, 264, 4096), (768, 768, 8192),
                                    (1152, 1152, 4096), (4608, 1152, 4096)])
-def test_gemm_wgrad_scratch_path(M, N, K):
+def test_gemm_wgrad_scratch_path(M, N, K, monkeypatch):
     """uwu_gemm_wgrad with split-K scratch (slices + reduce kernel) == exact matmul on integers, on top of existing C."""
     from uwudiff_amd import ops
+
+    monkeypatch.setenv("UWU_GEMM_TRW", "1")  # the wide kernel also for the short reductions of this list (K >= 4096)
 
     a, b = _operands(M, N, K, True, True, torch.bfloat16, ints=True, seed=13)
     want = a.float().t() @ b.float() + 2.0

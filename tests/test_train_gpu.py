@@ -148,7 +148,9 @@ def test_checkpoint_resume_reproduces_the_run(tmp_path):
     fit2.load_checkpoint = load_and_seed
     hist_b = fit2.fit(tr2, dm2, ckpt_path=path)
     assert fit2.global_step == 5 and len(hist_b) == 2
-    assert [h["loss"] for h in hist_b] == pytest.approx(tail_a, rel=1e-5)
+    # (fp32 atomics of the bias / split-K reductions add in a run-dependent order, the more so with the weight gradients of
+    #  small batches on their own stream: a few 1e-5 after two bf16 AdamW steps at lr 1e-3)
+    assert [h["loss"] for h in hist_b] == pytest.approx(tail_a, rel=1e-4)
     # (AdamW normalises every element's update to ~lr, so the last-bit run-to-run differences of the split-K atomics
     #  show up on the near-zero-gradient elements: compare in relative L2, not element-wise)
     assert float((tr2.unet.flat.detach() - flat_a).norm() / flat_a.norm()) < 1e-3

@@ -1826,7 +1826,10 @@ int trw_split(int tiles, int steps) {
 int pick_trw(const GemmArgs& g) {
   const char* e = getenv("UWU_GEMM_TRW");
   if (e && e[0] == '0') return 0;
-  if (g.K % 32 || g.K < 4096 || g.M % 8 || g.N % 8) return 0;
+  // short reductions (per-GPU batch < 128 images): the 4-stage ring of a whole-LDS workgroup barely fills and nothing else fits
+  // on its CU; the 256x128 kernel (two workgroups per CU) measured 1-2 % faster there.  UWU_GEMM_TRW=1 forces it (tests).
+  const bool force = e && e[0] == '1';
+  if (g.K % 32 || g.K < (force ? 4096 : 32768) || g.M % 8 || g.N % 8) return 0;
   if ((((uintptr_t)g.A | (uintptr_t)g.B) & 15) || g.lda % 8 || g.ldb % 8) return 0;
   if (g.N % 384 == 0 && g.M >= 192) return 1;
   if (g.M % 384 == 0 && g.N >= 192) return 2;
