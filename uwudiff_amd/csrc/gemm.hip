@@ -181,6 +181,7 @@ struct GemmArgs {
   const float* bias;
   const void* aux;
   int M, N, K, lda, ldb, ldc, ldaux, epi, tiles_m, tiles_n, k_tiles_per_split, wide;
+  int aux16;  // dGELU: aux rows are 16-byte addressable in the paired-lane layout of the wide stores (bf16, ldaux % 8 == 0)
   // implicit-GEMM 3x3 convolution (padding 1): geometry of the gathered operand (CONV template parameters)
   int cH, cW, cC, cHo, cWo, cS;  // input H x W x C (channels-last), output Ho x Wo, stride
   const void* zero;              // >= 16 zero bytes in device memory: the source of padded / out-of-range pixels
@@ -218,6 +219,24 @@ __device__ __forceinline__ void epi_load_aux_row(const GemmArgs& g, int m_w, int
   typedef typename EpiPre<T, FI, FJ>::AuxRaw AuxRaw;
   const T* aux = static_cast<const T*>(g.aux);
   const int m = m_w + 16 * i + fr;
+  if constexpr (sizeof(T) == 2 && FJ % 2 == 0) {
+    if (g.aux16) {
+      // one 16-byte load per PAIR of column fragments, in the lane layout of the wide stores (8 consecutive columns per
+      // lane: 64 contiguous bytes per row and instruction instead of 32, half the load instructions); the pair is
+      // un-swapped with v_permlane16_swap when the row is consumed (epi_unswap_aux), so the load itself stays asynchronous
+      const bool odd = fq & 1;
+#pragma unroll
+      for (int jp = 0; jp < FJ / 2; ++jp) {
+        const int nb = n_w + 32 * jp;
+        const int n = odd ? nb + 16 + 4 * (fq - 1) : nb + 4 * fq;
+        uint4 v = {0u, 0u, 0u, 0u};
+        if (m < g.M && n < g.N) v = *reinterpret_cast<const uint4*>(aux + (int64_t)m * g.ldaux + n);
+        dst[2 * jp] = AuxRaw{v.x, v.y};
+        dst[2 * jp + 1] = AuxRaw{v.z, v.w};
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int j = 0; j < FJ; ++j) {
     const int n = n_w + 16 * j + 4 * fq;
@@ -318,6 +337,18 @@ __device__ __forceinline__ void epilogue_tile(f32x4 (&acc)[FI][FJ], EpiPre<T, FI
     const int m = m_w + 16 * i + fr;
     const bool mok = m < g.M;
     AuxRaw(&arow)[FJ] = pre.aux[i % PD];
+    if constexpr (sizeof(T) == 2 && FJ % 2 == 0) {
+      if (dgelu && g.aux16) {  // paired 16-byte aux loads -> this lane's own 4 columns of both fragments (the swap is an involution)
+#pragma unroll
+        for (int jp = 0; jp < FJ / 2; ++jp) {
+          typedef unsigned su32x2 __attribute__((ext_vector_type(2)));
+          const su32x2 sx = __builtin_amdgcn_permlane16_swap(arow[2 * jp].x, arow[2 * jp + 1].x, false, false);
+          const su32x2 sy = __builtin_amdgcn_permlane16_swap(arow[2 * jp].y, arow[2 * jp + 1].y, false, false);
+          arow[2 * jp] = AuxRaw{sx[0], sy[0]};
+          arow[2 * jp + 1] = AuxRaw{sx[1], sy[1]};
+        }
+      }
+    }
     f32x4 v[FJ], sec[FJ];
 #pragma unroll
     for (int j = 0; j < FJ; ++j) {
@@ -2219,6 +2250,11 @@ extern "C" int uwu_gemm(const void* A, const void* B, void* C, void* C2, const f
   // 16-byte epilogue stores need 8-column granularity and 16-byte aligned rows
   g.wide = (!acc && c_dtype == UWU_BF16 && N % 8 == 0 && ldc % 8 == 0 && ((uintptr_t)C & 15) == 0 &&
             (C2 == nullptr || epilogue == UWU_EPI_DGELU || ((uintptr_t)C2 & 15) == 0)) ? 1 : 0;
+  g.aux16 = (epilogue == UWU_EPI_DGELU && dtype == UWU_BF16 && N % 8 == 0 && ldaux % 8 == 0 && ((uintptr_t)aux & 15) == 0) ? 1 : 0;
+  {
+    const char* e16 = getenv("UWU_GEMM_AUX16");  // "0": the 8-byte aux loads (A/B comparisons)
+    if (e16 && e16[0] == '0') g.aux16 = 0;
+  }
 
   const int ktiles = (K + bk - 1) / bk;
   int split = split_k < 1 ? 1 : split_k;
