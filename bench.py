@@ -272,6 +272,16 @@ def main():
     if rank == 0:
         print(f"[bench] timed region done: {elapsed / args.steps * 1e3:.3f} ms/step", file=sys.stderr, flush=True)
 
+    # ---- host side: wall time for the host to ENQUEUE one step (no sync inside); close to ms_per_step = launch-bound
+    host_ms = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step()
+        host_ms.append((time.perf_counter() - t0) * 1e3)
+    torch.cuda.synchronize()
+    host_enqueue_ms = round(sorted(host_ms)[1], 3)
+
     # ---- N > 1: how much of the gradient exchange is NOT hidden = step time with the exchange - step time without it
     # (same kernels, the all-reduce calls skipped; replicas drift apart afterwards, which no longer matters)
     comm = None
@@ -357,7 +367,8 @@ def main():
         line = {
             "metric": f"train images/sec (whole node), {args.model} {'256^2 latent' if args.latent == 32 else '4x128x128 latents'}", "value": round(value, 1),
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "host_enqueue_ms": host_enqueue_ms,
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.model} ({DESC[args.model]}), 4x{S}x{S} synthetic latents + pooled-text cond 1280, "
                                    f"eps-MSE, AdamW lr1e-6 wd0.01 cosine; random-init weights",

@@ -181,6 +181,7 @@ struct GemmArgs {
   const float* bias;
   const void* aux;
   int M, N, K, lda, ldb, ldc, ldaux, epi, tiles_m, tiles_n, k_tiles_per_split, wide;
+  int xs, nloc, part_m;  // gemm_tr_kernel: XCD partition (slice lanes, tiles per tile lane, tile lanes along m)
   int aux16;  // dGELU: aux rows are 16-byte addressable in the paired-lane layout of the wide stores (bf16, ldaux % 8 == 0)
   // implicit-GEMM 3x3 convolution (padding 1): geometry of the gathered operand (CONV template parameters)
   int cH, cW, cC, cHo, cWo, cS;  // input H x W x C (channels-last), output Ho x Wo, stride
@@ -1189,11 +1190,26 @@ __global__ void __launch_bounds__(256, 2) gemm_tr_kernel(const GemmArgs g) {
   // z = x, x+8, ... and walks the tiles of one slice before the next.  (With the plain (tile, z) grid the tiles of
   // a slice were spread over all 8 XCDs: PMC showed 73 % L2 misses and ~700 MB of fabric reads per launch for
   // 250 MB of operands.)  g.wide carries the number of slices.
-  const int nblk = g.tiles_m * g.tiles_n;
+  // Weights with MANY tiles and a short reduction (the UNet's Linears: 400 tiles, 192 K-steps) need no 8-fold split for
+  // parallelism, and 8 fp32 slices of such an output are far more traffic than the operands.  There the 8 XCDs form
+  // xs slice lanes x 8 / xs tile lanes: XCD x takes the slices z = (x mod xs) + xs j of the tiles whose row (part_m) or
+  // column index is congruent to x / xs -- an XCD still reads only its own share of one operand.  xs = 8 is the case above.
   const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
-  const int zsl = xcd + 8 * (loc / nblk), tile = loc % nblk;
+  const int sl = xcd & (g.xs - 1), tl = xcd / g.xs, TL = 8 / g.xs;
+  const int jz = loc / g.nloc, rr = loc - jz * g.nloc;
+  const int zsl = sl + g.xs * jz;
   if (zsl >= g.wide) return;  // uniform per block
-  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  int tm, tn;
+  if (g.part_m) {
+    const int u = rr / g.tiles_n;
+    tm = tl + TL * u;
+    tn = rr - u * g.tiles_n;
+  } else {
+    const int u = rr / g.tiles_m;
+    tn = tl + TL * u;
+    tm = rr - u * g.tiles_m;
+  }
+  if (tm >= g.tiles_m || tn >= g.tiles_n) return;  // uniform per block
   const int m0 = tm * TBM, n0 = tn * TBN;
   const int s_begin = zsl * g.k_tiles_per_split;  // K-steps of 32 rows
   int s_end = s_begin + g.k_tiles_per_split;
@@ -1348,6 +1364,22 @@ __global__ void __launch_bounds__(256, 2) gemm_tr_kernel(const GemmArgs g) {
     }
   }
   if constexpr (PART) {
+    if (g.wide == 1) {  // one slice: the tile is this workgroup's alone -> plain read-modify-write of C
+      float* C = static_cast<float*>(g.C);
+#pragma unroll
+      for (int i = 0; i < FI; ++i) {
+        const int m = m0 + wm * 16 * FI + 16 * i + fr;
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) {
+          const int n = n0 + wn * 16 * FJ + 16 * j + 4 * fq;
+          if (m < g.M && n < g.N) {
+            float* c = C + (int64_t)m * g.ldc + n;
+            store4(c, load4(c) + acc[i][j]);
+          }
+        }
+      }
+      return;
+    }
     float* P = static_cast<float*>(g.C2) + (int64_t)zsl * g.M * g.N;
 #pragma unroll
     for (int i = 0; i < FI; ++i) {
@@ -1797,14 +1829,34 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
 
 // Number of K slices for the streaming weight-gradient kernel: a multiple of 8 (one group of slices per XCD), as
 // many groups as fit the XCD's 64 workgroup slots (32 CUs x 2) in one round.
+// Outputs with >= 64 tiles of a reduction of a few thousand rows: fewer slices, the XCDs divided between slices and tiles
+// (gemm_tr_kernel's xs): every halving of the slice count halves the fp32 slice traffic.
 int tr_split(int tiles, int steps) {
-  int per_xcd = 64 / tiles;
-  if (per_xcd < 1) per_xcd = 1;
-  int split = 8 * per_xcd;
-  while (split > 8 && split * 4 > steps) split -= 8;  // keep >= 4 K-steps per slice
+  static int forced = -1;  // UWU_TR_SPLIT=n: sweeps
+  if (forced < 0) {
+    const char* e = getenv("UWU_TR_SPLIT");
+    forced = e ? atoi(e) : 0;
+  }
+  int split;
+  if (forced > 0) {
+    split = forced;
+  } else if (tiles >= 320 && steps <= 1024) {  // (sweep at 6144 / 24576 tokens: 400 tiles 361 -> 193 us, 200 tiles 166 -> 115,
+    split = 1;                                 //  150 tiles 122 -> 107, 100 tiles 223 -> 217; 50 tiles stay at 8 slices)
+  } else if (tiles >= 140 && steps <= 1024) {
+    split = 2;
+  } else if (tiles >= 80 && steps <= 1024) {
+    split = 4;
+  } else {
+    int per_xcd = 64 / tiles;
+    if (per_xcd < 1) per_xcd = 1;
+    split = 8 * per_xcd;
+    while (split > 8 && split * 4 > steps) split -= 8;  // keep >= 4 K-steps per slice
+  }
   if (split > steps) split = steps;
   return split < 1 ? 1 : split;
 }
+// slice lanes among the 8 XCDs: the largest power of two <= 8 that divides the slice count
+int tr_xs(int split) { return split % 8 == 0 ? 8 : (split % 4 == 0 ? 4 : (split % 2 == 0 ? 2 : 1)); }
 
 template <int FI, int FJ, bool CONVW = false>
 int launch_tr(GemmArgs g, void* scratch, size_t scratch_bytes, hipStream_t st) {
@@ -1822,13 +1874,24 @@ int launch_tr(GemmArgs g, void* scratch, size_t scratch_bytes, hipStream_t st) {
   int split = tr_split(tiles, steps);
   g.k_tiles_per_split = (steps + split - 1) / split;
   split = (steps + g.k_tiles_per_split - 1) / g.k_tiles_per_split;
+  // 16-byte rows in the scratch and in C: slices go to the scratch (one slice: straight into C); otherwise 8 slice lanes + atomics
+  const bool vec_ok = g.N % 4 == 0 && g.ldc % 4 == 0 && (((uintptr_t)g.C | (uintptr_t)scratch) & 15) == 0;
+  const bool part = vec_ok && (split == 1 || (scratch && scratch_bytes >= (size_t)split * g.M * g.N * sizeof(float)));
+  if (!part && split < 8 && steps >= 8) {  // the atomic path wants all XCDs through the slice lanes
+    split = 8;
+    g.k_tiles_per_split = (steps + split - 1) / split;
+    split = (steps + g.k_tiles_per_split - 1) / g.k_tiles_per_split;
+  }
   g.wide = split;
-  const int grid = 8 * tiles * ((split + 7) / 8);
-  // scratch path needs 16-byte rows in the scratch and in C
-  const bool part = scratch && split > 1 && g.N % 4 == 0 && g.ldc % 4 == 0 && (((uintptr_t)g.C | (uintptr_t)scratch) & 15) == 0 &&
-                    scratch_bytes >= (size_t)split * g.M * g.N * sizeof(float);
+  g.xs = tr_xs(split);
+  const int TL = 8 / g.xs;
+  g.part_m = g.tiles_m >= g.tiles_n;
+  g.nloc = g.part_m ? ((g.tiles_m + TL - 1) / TL) * g.tiles_n : ((g.tiles_n + TL - 1) / TL) * g.tiles_m;
+  const int grid = 8 * g.nloc * ((split + g.xs - 1) / g.xs);
   UwuProfScope prof(st);
-  if (part) {
+  if (part && split == 1) {
+    hipLaunchKernelGGL((gemm_tr_kernel<FI, FJ, true, CONVW>), dim3(grid), dim3(256), T_NST * T_STAGE, st, g);
+  } else if (part) {
     g.C2 = scratch;
     hipLaunchKernelGGL((gemm_tr_kernel<FI, FJ, true, CONVW>), dim3(grid), dim3(256), T_NST * T_STAGE, st, g);
     const int64_t quads = (int64_t)g.M * g.N / 4;

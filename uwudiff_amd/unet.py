@@ -16,7 +16,9 @@ SDXL shape.  This module keeps the call contract (diffusion.py:172-176), diffuse
 The graph is composed in Python (one ``autograd.Function`` per fused op); unlike the DiT there is no C++ driver yet,
 so small batches are host-bound -- the next step for this model is a driver like csrc/dit.cpp.
 """
+import collections
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -59,14 +61,55 @@ class _Ctx:
         self.flat = None
         self.shadow = None
         self.bf16 = True
+        self.side = None
+        self._join_queued = False
+        self._held = collections.deque()
+
+    # ---- weight gradients are off the backward's critical path: they run on a side stream, ordered after the kernels
+    # that produced their operands; the main stream joins once, when the backward pass has finished
+    def on_side(self, fn, *operands):
+        side = self.side
+        if side is None:
+            return fn()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+            done = torch.cuda.Event()
+            done.record(side)
+        # The operands stay referenced until the side stream has read them: the allocator cannot hand their memory out, and
+        # autograd -- which sums a second gradient INTO a tensor it holds the only reference to -- cannot rewrite them
+        # (an output gradient returned to two producers was overwritten on the main stream while its wgrad was reading it).
+        self._held.append((done, operands))
+        while self._held and self._held[0][0].query():
+            self._held.popleft()
+        if not self._join_queued:
+            self._join_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._join)
+
+    def _join(self):
+        self._join_queued = False
+        torch.cuda.current_stream().wait_stream(self.side)
 
     def add(self, name, shape):
         self.registry[name] = (self.n, tuple(shape))
         self.n += _pad64(math.prod(shape))
 
     def _view(self, buf, name):
+        if isinstance(name, tuple):  # (first name, n): n equally shaped matrices stored back to back, seen as one
+            first, n = name
+            off, (rows, cols) = self.registry[first]
+            return buf[off:off + n * rows * cols].view(n * rows, cols)
         off, shape = self.registry[name]
         return buf[off:off + math.prod(shape)].view(shape)
+
+    def span(self, names):
+        """(first, n) when `names` sit back to back with no padding between them (one stacked GEMM operand), else None"""
+        off, shape = self.registry[names[0]]
+        for i, nm in enumerate(names):
+            o, sh = self.registry[nm]
+            if sh != shape or len(sh) != 2 or o != off + i * math.prod(shape):
+                return None
+        return (names[0], len(names))
 
     def w32(self, name):
         return self._view(self.flat.data, name)
@@ -116,7 +159,8 @@ class _LinearFn(torch.autograd.Function):
         N = W.shape[0]
         dx = ops.gemm(dy, W, trans_b=True) if ctx.needs_input_grad[0] else None
         # dW += dy^T x and db += colsum(dy) in one launch where the streaming kernel takes the shape
-        ops.gemm_wgrad_shared(dy, x, P.g(wname), blocks=_wgrad_blocks(M, N, K), bias_grad=P.g(bname) if bname else None)
+        P.on_side(lambda: ops.gemm_wgrad_shared(dy, x, P.g(wname), blocks=_wgrad_blocks(M, N, K),
+                                                bias_grad=P.g(bname) if bname else None), dy, x)
         return dx, None, None, None, None, None
 
 
@@ -147,7 +191,7 @@ class _Conv3x3Fn(torch.autograd.Function):
             Cout = Wt.shape[0]
             if ctx.needs_input_grad[0]:
                 dx = ops.conv3x3_dgrad(dy, Wt, B, H, W_, C, Cout, stride)
-            ops.conv3x3_wgrad(dy, x, P.g(wname), P.g(bname), B, H, W_, C, Cout, stride)
+            P.on_side(lambda: ops.conv3x3_wgrad(dy, x, P.g(wname), P.g(bname), B, H, W_, C, Cout, stride), dy, x)
             return (dx,) + (None,) * 8
         if ctx.needs_input_grad[0]:
             dcol = ops.gemm(dy, Wt, trans_b=True)
@@ -195,6 +239,30 @@ class _LayerNormFn(torch.autograd.Function):
         return dx, None, None, None
 
 
+class _AddLayerNormFn(torch.autograd.Function):
+    """(x, n) = (h + a, LN(h + a)) in one pass; backward folds the residual gradient into the LayerNorm backward
+    (dx = dx_res + LN_bwd(dn)), so neither direction runs a separate add."""
+
+    @staticmethod
+    def forward(ctx, h, a, P, prefix, eps, ones):
+        M, D = h.shape
+        x, n, mean, rstd = ops.add_ln_modulate_fwd(h, 1, M, y=a.contiguous(), gate=ones, shift=P.w32(prefix + ".bias"),
+                                                   scale=P.w32(prefix + ".weight"), mod_ld=0, eps=eps, affine=True)
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.meta = (P, prefix)
+        return x, n
+
+    @staticmethod
+    def backward(ctx, dx_res, dn):
+        x, mean, rstd = ctx.saved_tensors
+        P, prefix = ctx.meta
+        M, D = x.shape
+        dx, _ = ops.add_ln_modulate_bwd(dn.contiguous(), x, mean, rstd, 1, M, scale=P.w32(prefix + ".weight"),
+                                        dx_in=dx_res.contiguous(), mod_ld=0, dshift=P.g(prefix + ".bias"),
+                                        dscale=P.g(prefix + ".weight"), affine=True)
+        return dx, dx, None, None, None, None
+
+
 class _AttentionFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, B, Tq, Tk, H, d, key_bias=None):
@@ -210,6 +278,41 @@ class _AttentionFn(torch.autograd.Function):
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         ops.attention_bwd(q, k, v, o, do.contiguous(), lse, dq, dk, dv, B, Tq, Tk, H, d, key_bias=key_bias)
         return dq, dk, dv, None, None, None, None, None, None
+
+
+class _PackedAttentionFn(torch.autograd.Function):
+    """attention over stacked projections: `a` is [M, 3D] (q|k|v, self-attention) or q comes separately and `a` is the
+    context's [Mk, 2D] (k|v).  The gradient of the stacked tensor is written in place by the backward kernel, so the
+    three (two) projections cost one dgrad and one wgrad GEMM and no gradient summation."""
+
+    @staticmethod
+    def forward(ctx, q, a, B, Tq, Tk, H, d, key_bias=None):
+        D = H * d
+        if q is None:
+            qv, kv, vv = a[:, :D], a[:, D:2 * D], a[:, 2 * D:]
+        else:
+            qv, kv, vv = q, a[:, :D], a[:, D:]
+        o, lse = ops.attention_fwd(qv, kv, vv, B, Tq, Tk, H, d, key_bias=key_bias)
+        ctx.save_for_backward(q, a, o, lse)
+        ctx.meta = (B, Tq, Tk, H, d, key_bias)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, a, o, lse = ctx.saved_tensors
+        B, Tq, Tk, H, d, key_bias = ctx.meta
+        D = H * d
+        da = torch.empty_like(a)
+        if q is None:
+            dq = None
+            qv, kv, vv = a[:, :D], a[:, D:2 * D], a[:, 2 * D:]
+            dqv, dkv, dvv = da[:, :D], da[:, D:2 * D], da[:, 2 * D:]
+        else:
+            dq = torch.empty_like(q)
+            qv, kv, vv = q, a[:, :D], a[:, D:]
+            dqv, dkv, dvv = dq, da[:, :D], da[:, D:]
+        ops.attention_bwd(qv, kv, vv, o, do.contiguous(), lse, dqv, dkv, dvv, B, Tq, Tk, H, d, key_bias=key_bias)
+        return dq, da, None, None, None, None, None, None
 
 
 class _GegluFn(torch.autograd.Function):
@@ -546,6 +649,12 @@ class UNet2DConditionModel(nn.Module):
         return None
 
     # ------------------------------------------------------------------ blocks
+    def _ones(self, n, dev):
+        c = self.__dict__.setdefault("_ones_cache", {})
+        if (n, dev) not in c:
+            c[(n, dev)] = torch.ones(n, device=dev, dtype=torch.float32)
+        return c[(n, dev)]
+
     def _linear(self, x, name, bias=True, fp32=False):
         return _LinearFn.apply(x, self.P, name + ".weight", name + ".bias" if bias else None, fp32, self.flat)
 
@@ -566,6 +675,21 @@ class UNet2DConditionModel(nn.Module):
 
     def _attn(self, x, ctx, name, B, T, Tk, heads, key_bias=None):
         D = x.shape[1]
+        # q|k|v (self-attention) and k|v (cross-attention) weights sit back to back in the flat buffer: one stacked
+        # projection instead of three (two), forward and backward
+        if ctx is None:
+            span = self.P.span([f"{name}.to_{c}.weight" for c in "qkv"])
+            if span is not None:
+                qkv = _LinearFn.apply(x, self.P, span, None, False, self.flat)
+                o = _PackedAttentionFn.apply(None, qkv, B, T, Tk, heads, D // heads, key_bias)
+                return self._linear(o, name + ".to_out.0")
+        else:
+            span = self.P.span([f"{name}.to_{c}.weight" for c in "kv"])
+            if span is not None:
+                q = self._linear(x, name + ".to_q", bias=False)
+                kv = _LinearFn.apply(ctx, self.P, span, None, False, self.flat)
+                o = _PackedAttentionFn.apply(q, kv, B, T, Tk, heads, D // heads, key_bias)
+                return self._linear(o, name + ".to_out.0")
         q = self._linear(x, name + ".to_q", bias=False)
         src = x if ctx is None else ctx
         k = self._linear(src, name + ".to_k", bias=False)
@@ -576,16 +700,20 @@ class UNet2DConditionModel(nn.Module):
     def _t2d(self, x, ctx, name, depth, heads, B, HW, C, Tk):
         h = _GroupNormFn.apply(x, self.P, name + ".norm", B, HW, C, self.G, 1e-6, False)
         h = self._linear(h, name + ".proj_in")
+        ones = self._ones(C, h.device)
+        f = None  # branch output still to be added to the residual stream: folded into the next LayerNorm pass
         for i in range(depth):
             b = f"{name}.transformer_blocks.{i}"
-            a = self._attn(_LayerNormFn.apply(h, self.P, b + ".norm1", 1e-5), None, b + ".attn1", B, HW, HW, heads)
-            h = _AddFn.apply(h, a)
-            a = self._attn(_LayerNormFn.apply(h, self.P, b + ".norm2", 1e-5), ctx, b + ".attn2", B, HW, Tk, heads,
-                           self._key_bias)
-            h = _AddFn.apply(h, a)
-            f = self._linear(_LayerNormFn.apply(h, self.P, b + ".norm3", 1e-5), b + ".ff.net.0.proj")
-            f = self._linear(_GegluFn.apply(f), b + ".ff.net.2")
-            h = _AddFn.apply(h, f)
+            if f is None:
+                n = _LayerNormFn.apply(h, self.P, b + ".norm1", 1e-5)
+            else:
+                h, n = _AddLayerNormFn.apply(h, f, self.P, b + ".norm1", 1e-5, ones)
+            a = self._attn(n, None, b + ".attn1", B, HW, HW, heads)
+            h, n = _AddLayerNormFn.apply(h, a, self.P, b + ".norm2", 1e-5, ones)
+            a = self._attn(n, ctx, b + ".attn2", B, HW, Tk, heads, self._key_bias)
+            h, n = _AddLayerNormFn.apply(h, a, self.P, b + ".norm3", 1e-5, ones)
+            f = self._linear(_GegluFn.apply(self._linear(n, b + ".ff.net.0.proj")), b + ".ff.net.2")
+        h = _AddFn.apply(h, f)
         h = self._linear(h, name + ".proj_out")
         return _AddFn.apply(h, x)
 
@@ -602,6 +730,8 @@ class UNet2DConditionModel(nn.Module):
             self.refresh_shadow()
         if self.flat.grad is None and torch.is_grad_enabled():
             self.flat.grad = torch.zeros_like(self.flat.data)
+        if P.side is None and os.environ.get("UWU_UNET_FORK", "1") != "0":
+            P.side = torch.cuda.Stream(device=dev)
         if not torch.is_tensor(timestep):
             timestep = torch.tensor([timestep], device=dev)
         t = timestep.to(dev).float().reshape(-1).expand(B).contiguous()
