@@ -192,6 +192,86 @@ __global__ void __launch_bounds__(256) add_ln_mod_bwd_kernel(
   }
 }
 
+// LayerNorm backward with ONE weight / bias vector for all rows (the UNet's transformer blocks; the adaLN form above has a
+// shift / scale per sample).  With per-sample vectors the column sums of a workgroup go to B x D different addresses;
+// here every workgroup adds to the same 2 D floats, and the kernel above -- few rows per workgroup to fill the chip --
+// issued 1536 x 2560 global atomics at M = 6144, D = 1280 (50 us for 63 MB of traffic; 16 rows per workgroup: 31 us).
+// This one: 8 waves x 4..8 rows per workgroup, one global atomic per column per workgroup.
+template <typename T, int MAX_IT>
+__global__ void __launch_bounds__(512) ln_affine_bwd_kernel(
+    const T* __restrict__ dh, const T* __restrict__ x, const float* __restrict__ mean_i,
+    const float* __restrict__ rstd_i, const float* __restrict__ weight, const T* __restrict__ dx_in,
+    T* __restrict__ dx_out, float* __restrict__ dbias, float* __restrict__ dweight, int M, int D, int rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [8 waves][2][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nit = (D + 511) >> 9;
+  const int row0 = blockIdx.x * rows_per_block;
+  f32x8 a_sh[MAX_IT], a_sc[MAX_IT], wv[MAX_IT];
+#pragma unroll
+  for (int it = 0; it < MAX_IT; ++it) {
+    a_sh[it] = a_sc[it] = f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int d = it * 512 + lane * 8;
+    wv[it] = (it < nit && d < D) ? load8(weight + d) : a_sh[it];
+  }
+  for (int r = wave; r < rows_per_block; r += 8) {
+    const int row = row0 + r;
+    if (row >= M) break;
+    const int64_t off = (int64_t)row * D;
+    const float mean = mean_i[row], rstd = rstd_i[row];
+    f32x8 xh[MAX_IT], g[MAX_IT], din[MAX_IT];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it) {
+      const int d = it * 512 + lane * 8;
+      if (it < nit && d < D) {
+        const f32x8 xv = load8_nt(x + off + d), dv = load8(dh + off + d);
+        if (dx_in) din[it] = load8_nt(dx_in + off + d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xhat = (xv[e] - mean) * rstd, gg = dv[e] * wv[it][e];
+          xh[it][e] = xhat;
+          g[it][e] = gg;
+          s1 += gg;
+          s2 += gg * xhat;
+          a_sh[it][e] += dv[e];
+          a_sc[it][e] += dv[e] * xhat;
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it) {
+      const int d = it * 512 + lane * 8;
+      if (it < nit && d < D) {
+        f32x8 dx;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dx[e] = rstd * (g[it][e] - s1 - xh[it][e] * s2);
+        if (dx_in) dx = dx + din[it];
+        store8_nt(dx_out + off + d, dx);
+      }
+    }
+  }
+  // fold the 8 waves' column sums (private [2][D] slabs, then 512 threads add the slabs: consecutive lanes, consecutive
+  // columns -- coalesced global atomics; LDS float atomics into one slab measured 3x slower than the whole old kernel)
+  float* mine = red + (int64_t)wave * 2 * D;
+#pragma unroll
+  for (int it = 0; it < MAX_IT; ++it) {
+    const int d = it * 512 + lane * 8;
+    if (it < nit && d < D) {
+      store8(mine + d, a_sh[it]);
+      store8(mine + D + d, a_sc[it]);
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * D; c += 512) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) t += red[w * 2 * D + c];
+    atomicAdd(c < D ? dbias + c : dweight + (c - D), t);
+  }
+}
+
 // out[n] += sum_m X[m,n]: 16 row-lanes x 16 column-groups(4 cols) per workgroup, rows split over gridDim.y
 template <typename T>
 __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ X, int M, int N, int ldx,
@@ -267,15 +347,79 @@ extern "C" int uwu_add_ln_modulate_bwd(const void* dh, const void* x, const floa
   UWU_CHECK_ARG((((uintptr_t)dh | (uintptr_t)x | (uintptr_t)dx_out) & 15) == 0, "add_ln_modulate_bwd: tensors must be 16-byte aligned");
   UWU_CHECK_ARG((y == nullptr) || (gate && dy), "add_ln_modulate_bwd: y needs gate and dy");
   UWU_CHECK_ARG(!(scale || y) || mod_ld % 4 == 0, "add_ln_modulate_bwd: mod_ld must be a multiple of 4");
+  const int M = B * T;
+  hipStream_t st = (hipStream_t)stream;
+  UWU_CHECK_ARG(dtype == UWU_F32 || dtype == UWU_BF16, "add_ln_modulate_bwd: bad dtype");
+  static int aff_on = -1;  // UWU_LN_AFFINE=0: the per-sample kernel for every case (A/B comparisons)
+  if (aff_on < 0) {
+    const char* e = getenv("UWU_LN_AFFINE");
+    aff_on = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (aff_on && affine && mod_ld == 0 && scale && !y && dshift && dscale && D <= 2048 && (dx_in == nullptr || ((uintptr_t)dx_in & 15) == 0)) {
+    // one weight / bias vector for every row: 8-wave workgroups, LDS-folded column sums
+    int rpb = M >= 16384 ? 64 : (M >= 4096 ? 32 : 16);
+    {
+      static int forced = -1;
+      if (forced < 0) {
+        const char* e = getenv("UWU_LN_ROWS");
+        forced = e ? atoi(e) : 0;
+      }
+      if (forced > 0) rpb = forced;
+    }
+    const int grid = (M + rpb - 1) / rpb;
+    const size_t lds2 = (size_t)8 * 2 * D * sizeof(float);
+    if (lds2 > 64 * 1024) {
+      static bool done_f = false, done_b = false;
+      bool& done = dtype == UWU_F32 ? done_f : done_b;
+      if (!done) {
+        for (int nit = 1; nit <= 4; ++nit) {
+          const void* kf = nullptr;
+          if (dtype == UWU_F32)
+            kf = nit == 1 ? (const void*)ln_affine_bwd_kernel<float, 1> : nit == 2 ? (const void*)ln_affine_bwd_kernel<float, 2>
+                 : nit == 3 ? (const void*)ln_affine_bwd_kernel<float, 3> : (const void*)ln_affine_bwd_kernel<float, 4>;
+          else
+            kf = nit == 1 ? (const void*)ln_affine_bwd_kernel<bf16_t, 1> : nit == 2 ? (const void*)ln_affine_bwd_kernel<bf16_t, 2>
+                 : nit == 3 ? (const void*)ln_affine_bwd_kernel<bf16_t, 3> : (const void*)ln_affine_bwd_kernel<bf16_t, 4>;
+          (void)hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        }
+        done = true;
+      }
+    }
+    UwuProfScope prof(stream);
+#define AFF_CASE(NIT)                                                                                                   \
+  case NIT:                                                                                                             \
+    if (dtype == UWU_F32)                                                                                               \
+      hipLaunchKernelGGL((ln_affine_bwd_kernel<float, NIT>), dim3(grid), dim3(512), lds2, st, (const float*)dh,         \
+                         (const float*)x, mean, rstd, scale, (const float*)dx_in, (float*)dx_out, dshift, dscale, M, D, \
+                         rpb);                                                                                          \
+    else                                                                                                                \
+      hipLaunchKernelGGL((ln_affine_bwd_kernel<bf16_t, NIT>), dim3(grid), dim3(512), lds2, st, (const bf16_t*)dh,       \
+                         (const bf16_t*)x, mean, rstd, scale, (const bf16_t*)dx_in, (bf16_t*)dx_out, dshift, dscale, M, \
+                         D, rpb);                                                                                       \
+    break;
+    switch ((D + 511) / 512) {
+      AFF_CASE(1) AFF_CASE(2) AFF_CASE(3) AFF_CASE(4)
+    }
+#undef AFF_CASE
+    const double e = dtype == UWU_BF16 ? 2.0 : 4.0, md = (double)M * D;
+    prof.done(UWU_PROF_LN_BWD, dtype == UWU_BF16 ? 0 : 1, 16.0 * md, md * e * (3 + (dx_in ? 1 : 0)));
+    UWU_LAUNCH_CHECK("ln_affine_bwd");
+    return UWU_OK;
+  }
   int rows = 32;
   while (rows > 1 && T % rows) rows >>= 1;
-  const int M = B * T;
   // small batches: fewer rows per workgroup (down to one per wave) until the grid has ~4 workgroups per CU -- at
   // M = 4096 the 128 workgroups of 32 rows took 18.5 us, most of it eight dependent row passes per wave
   while (rows > 4 && M / rows < 1024) rows >>= 1;
+  {
+    static int forced = -1;
+    if (forced < 0) {
+      const char* e = getenv("UWU_LN_ROWS");
+      forced = e ? atoi(e) : 0;
+    }
+    if (forced > 0 && T % forced == 0) rows = forced;
+  }
   const size_t lds = (size_t)4 * 3 * D * sizeof(float);
-  hipStream_t st = (hipStream_t)stream;
-  UWU_CHECK_ARG(dtype == UWU_F32 || dtype == UWU_BF16, "add_ln_modulate_bwd: bad dtype");
   UWU_CHECK_ARG(lds <= 160 * 1024, "add_ln_modulate_bwd: D=%d needs %zu B of LDS (> 160 KB)", D, lds);
   UwuProfScope prof(stream);
 #define BWD_CASE(NIT)                                                                                               \
