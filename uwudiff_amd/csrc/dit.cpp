@@ -122,7 +122,9 @@ Layout make_layout(const uwu_dit_desc& d) {
                            uwu_gemm_fp8_scratch_bytes((int)L.D3, d.D, (int)L.M), uwu_gemm_fp8_scratch_bytes(d.D, d.D, (int)L.M)})
       if (t > L.wsc_bytes) L.wsc_bytes = t;
   }
-  L.wsc = take(L.wsc_bytes);
+  L.wsc_bytes = (L.wsc_bytes + 255) & ~(size_t)255;
+  // forked backward (small batches): the four weight gradients of a block run on four streams, each with its own slices
+  L.wsc = take(L.wsc_bytes * (L.M <= 16384 ? 4 : 1));
   if (d.fp8) {
     L.x8 = take(L.M * L.D4);
     L.x8t = 0;
@@ -280,32 +282,43 @@ int f8_bwd(const F8& f, const void* dY, const void* X8t, const void* W8t, float*
 // by the next LayerNorm backward, du / dqkv by the next block).  At large batches the kernels fill the chip by themselves
 // and concurrent launches only time-slice (measured round 1: -7 % .. +7 %), so the fork is taken for M <= 16384 only.
 struct Fork {
-  hipStream_t main, side;
-  hipEvent_t ev[8];  // 0-3: producer done (recorded on main); 4-7: consumer done (recorded on side)
+  hipStream_t main;
+  hipStream_t side[4];  // one per weight gradient of a block (qkv's = the caller's side stream, which carries layer_done)
+  hipEvent_t ev[8];     // 0-3: producer done (recorded on main); 4-7: consumer done (recorded on side[slot])
   bool on = false;
 };
-bool fork_events(hipEvent_t (&ev)[8]) {
+bool fork_resources(Fork& f, hipStream_t caller_side) {
   static hipEvent_t pool[8];
+  static hipStream_t extra[3];
   static bool made = false;
   if (!made) {
     for (auto& e : pool)
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+    for (auto& x : extra)
+      if (hipStreamCreateWithFlags(&x, hipStreamNonBlocking) != hipSuccess) return false;
     made = true;
   }
-  for (int i = 0; i < 8; ++i) ev[i] = pool[i];
+  for (int i = 0; i < 8; ++i) f.ev[i] = pool[i];
+  static int n_side = -1;  // UWU_DIT_SIDE_STREAMS=1: every weight gradient on the caller's side stream (A/B comparisons)
+  if (n_side < 0) {
+    const char* e = getenv("UWU_DIT_SIDE_STREAMS");
+    n_side = (e && e[0] == '1') ? 1 : 4;
+  }
+  for (int i = 0; i < 3; ++i) f.side[i] = n_side == 1 ? caller_side : extra[i];
+  f.side[3] = caller_side;
   return true;
 }
-// side stream: wait for `produced` (recorded on main now), run fn there, record `consumed`
+// side stream `slot`: wait for `produced` (recorded on main now), run fn there, record `consumed`
 template <typename F>
 int on_side(const Fork& f, int slot, F&& fn) {
-  if (!f.on) return fn(static_cast<void*>(f.main));
-  if (hipEventRecord(f.ev[slot], f.main) != hipSuccess || hipStreamWaitEvent(f.side, f.ev[slot], 0) != hipSuccess) {
+  if (!f.on) return fn(static_cast<void*>(f.main), 0);
+  if (hipEventRecord(f.ev[slot], f.main) != hipSuccess || hipStreamWaitEvent(f.side[slot], f.ev[slot], 0) != hipSuccess) {
     uwu_set_error("dit_backward: stream fork failed");
     return UWU_ELAUNCH;
   }
-  const int rc = fn(static_cast<void*>(f.side));
+  const int rc = fn(static_cast<void*>(f.side[slot]), f.side[slot] == f.side[3] ? 0 : slot + 1);
   if (rc != UWU_OK) return rc;
-  if (hipEventRecord(f.ev[4 + slot], f.side) != hipSuccess) { uwu_set_error("dit_backward: stream fork failed"); return UWU_ELAUNCH; }
+  if (hipEventRecord(f.ev[4 + slot], f.side[slot]) != hipSuccess) { uwu_set_error("dit_backward: stream fork failed"); return UWU_ELAUNCH; }
   return UWU_OK;
 }
 // main stream: do not overwrite a buffer before the side stream's consumer `slot` of it has finished
@@ -505,8 +518,10 @@ extern "C" int uwu_dit_backward(const uwu_dit_desc* dp, const float* dout, void*
   const float scale = 1.f / sqrtf((float)(D / d.H));
   const F8 f8{d.fp8, d.f8_scale, d.f8_amax, d.f8_fmt, P.at<char>(L.x8), nullptr, P.at<char>(L.dy8),
               P.at<char>(L.dy8t), P.at<char>(L.wsc), P.at<char>(L.w8), L.wsc_bytes, L.w8_layer, d.D, st};
-  Fork fk{static_cast<hipStream_t>(st), static_cast<hipStream_t>(d.side_stream), {}, false};
-  fk.on = d.side_stream && d.side_stream != st && !d.fp8 && dt == UWU_BF16 && M <= 16384 && fork_events(fk.ev);
+  Fork fk{static_cast<hipStream_t>(st), {}, {}, false};
+  fk.on = d.side_stream && d.side_stream != st && !d.fp8 && dt == UWU_BF16 && M <= 16384 &&
+          fork_resources(fk, static_cast<hipStream_t>(d.side_stream));
+  char* const wsc = P.at<char>(L.wsc);  // region k of the split-K scratch belongs to the stream that fn(.., k) runs on
   bool side_used[4] = {false, false, false, false};  // a consumer-done event of this slot has been recorded in this call
 
   // ---- output head
@@ -537,16 +552,16 @@ extern "C" int uwu_dit_backward(const uwu_dit_desc* dp, const float* dout, void*
       RUN(f8_bwd(f8, P.at(L.du), P.lay(l, L.o_h2t), f8.w(l, 2, true), g + w.off_fc1_w, nullptr, P.at(L.dh), nullptr, nullptr, M, D4, D,
                  f8.role(l, 6), f8.role(l, 2), f8.role(l, 10)));
     } else {
-    RUN(on_side(fk, 0, [&](void* s2) {
-      return lin_wgrad(P.at(L.dy), P.lay(l, L.o_f), g + w.off_fc2_w, M, D, D4, dt, s2, P.at(L.wsc), L.wsc_bytes, g + w.off_fc2_b);
+    RUN(on_side(fk, 0, [&](void* s2, int k) {
+      return lin_wgrad(P.at(L.dy), P.lay(l, L.o_f), g + w.off_fc2_w, M, D, D4, dt, s2, wsc + (size_t)k * L.wsc_bytes, L.wsc_bytes, g + w.off_fc2_b);
     }));
     side_used[0] = true;
     if (side_used[1]) RUN(join_side(fk, 1));  // the previous block's fc1 weight gradient still reads du
     // du = (dy.W2) * gelu'(u).  The fc1 bias gradient = colsum(du) comes out of the fc1 weight-gradient kernel (extra MFMAs
     // against an all-ones fragment, free there) -- as fp32 atomics in this epilogue it cost 79 us per launch at B = 768
     RUN(lin_dgrad(P.at(L.dy), w.fc2_w, P.at(L.du), P.lay(l, L.o_u), M, D, D4, dt, st, nullptr));
-    RUN(on_side(fk, 1, [&](void* s2) {
-      return lin_wgrad(P.at(L.du), P.lay(l, L.o_h2), g + w.off_fc1_w, M, D4, D, dt, s2, P.at(L.wsc), L.wsc_bytes, g + w.off_fc1_b);
+    RUN(on_side(fk, 1, [&](void* s2, int k) {
+      return lin_wgrad(P.at(L.du), P.lay(l, L.o_h2), g + w.off_fc1_w, M, D4, D, dt, s2, wsc + (size_t)k * L.wsc_bytes, L.wsc_bytes, g + w.off_fc1_b);
     }));
     side_used[1] = true;
     RUN(lin_dgrad(P.at(L.du), w.fc1_w, P.at(L.dh), nullptr, M, D4, D, dt, st));
@@ -561,8 +576,8 @@ extern "C" int uwu_dit_backward(const uwu_dit_desc* dp, const float* dout, void*
       RUN(f8_bwd(f8, P.at(L.dy), P.lay(l, L.o_aot), f8.w(l, 1, true), g + w.off_o_w, g + w.off_o_b, P.at(L.dao), nullptr, nullptr, M, D, D,
                  f8.role(l, 5), f8.role(l, 1), f8.role(l, 9)));
     } else {
-    RUN(on_side(fk, 2, [&](void* s2) {
-      return lin_wgrad(P.at(L.dy), P.lay(l, L.o_ao), g + w.off_o_w, M, D, D, dt, s2, P.at(L.wsc), L.wsc_bytes, g + w.off_o_b);
+    RUN(on_side(fk, 2, [&](void* s2, int k) {
+      return lin_wgrad(P.at(L.dy), P.lay(l, L.o_ao), g + w.off_o_w, M, D, D, dt, s2, wsc + (size_t)k * L.wsc_bytes, L.wsc_bytes, g + w.off_o_b);
     }));
     side_used[2] = true;
     RUN(lin_dgrad(P.at(L.dy), w.o_w, P.at(L.dao), nullptr, M, D, D, dt, st));
@@ -589,15 +604,21 @@ extern "C" int uwu_dit_backward(const uwu_dit_desc* dp, const float* dout, void*
       RUN(f8_bwd(f8, dqkv, P.lay(l, L.o_h1t), f8.w(l, 0, true), g + w.off_qkv_w, g + w.off_qkv_b, P.at(L.dh), nullptr, nullptr, M, D3, D,
                  f8.role(l, 4), f8.role(l, 0), f8.role(l, 8)));
     } else {
-    RUN(on_side(fk, 3, [&](void* s2) {
-      return lin_wgrad(dqkv, P.lay(l, L.o_h1), g + w.off_qkv_w, M, D3, D, dt, s2, P.at(L.wsc), L.wsc_bytes, g + w.off_qkv_b);
+    RUN(on_side(fk, 3, [&](void* s2, int k) {
+      return lin_wgrad(dqkv, P.lay(l, L.o_h1), g + w.off_qkv_w, M, D3, D, dt, s2, wsc + (size_t)k * L.wsc_bytes, L.wsc_bytes, g + w.off_qkv_b);
     }));
     side_used[3] = true;
     }
     // every parameter gradient of block l is now in flight (on the side stream when the backward is forked: its launches
     // are in order, so the last weight gradient's stream carries the event)
+    if (fk.on && d.layer_done && d.layer_done[l])
+      for (int k = 0; k < 3; ++k)
+        if (fk.side[k] != fk.side[3] && hipStreamWaitEvent(fk.side[3], fk.ev[4 + k], 0) != hipSuccess) {
+          uwu_set_error("dit_backward: stream join failed");
+          return UWU_ELAUNCH;
+        }
     if (d.layer_done && d.layer_done[l] &&
-        hipEventRecord(static_cast<hipEvent_t>(d.layer_done[l]), fk.on ? fk.side : static_cast<hipStream_t>(st)) != hipSuccess) {
+        hipEventRecord(static_cast<hipEvent_t>(d.layer_done[l]), fk.on ? fk.side[3] : static_cast<hipStream_t>(st)) != hipSuccess) {
       uwu_set_error("dit_backward: hipEventRecord(layer_done[%d]) failed", l);
       return UWU_ELAUNCH;
     }
@@ -615,7 +636,8 @@ extern "C" int uwu_dit_backward(const uwu_dit_desc* dp, const float* dout, void*
                                   P.at(L.dx), nullptr, nullptr, ML, P.at(L.dx), nullptr, dm + 0, dm + D, nullptr, B, T, D, 0, dt, st));
     }
   }
-  if (fk.on) RUN(join_side(fk, 3));  // the side stream is in order: its last weight gradient ends it
+  if (fk.on)
+    for (int k = 0; k < 4; ++k) RUN(join_side(fk, k));  // each side stream is in order: its last weight gradient ends it
   // ---- patch embedding (input latents need no gradient; positions are fixed)
   RUN(lin_wgrad(P.at(L.dx), P.at(L.tok), g + d.off_patch_w, M, D, (int)L.Kp, dt, st));
   RUN(uwu_colsum(P.at(L.dx), dt, M, D, D, g + d.off_patch_b, 1, st));

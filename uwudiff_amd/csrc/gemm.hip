@@ -1850,7 +1850,12 @@ int tr_split(int tiles, int steps) {
     int per_xcd = 64 / tiles;
     if (per_xcd < 1) per_xcd = 1;
     split = 8 * per_xcd;
-    while (split > 8 && split * 4 > steps) split -= 8;  // keep >= 4 K-steps per slice
+    static int min_steps = -1;  // UWU_TR_MINSTEPS=n: sweeps
+    if (min_steps < 0) {
+      const char* e = getenv("UWU_TR_MINSTEPS");
+      min_steps = e ? atoi(e) : 32;
+    }
+    while (split > 8 && split * min_steps > steps) split -= 8;  // keep >= 32 K-steps per slice (batch 16: 3.82k -> 4.13k img/s, batch 64: 9.05k -> 9.79k with the four side streams)
   }
   if (split > steps) split = steps;
   return split < 1 ? 1 : split;
