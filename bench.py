@@ -153,7 +153,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=DEFAULT_BATCH, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help=f"per-GPU batch (weak scaling); default {DEFAULT_BATCH} (DiT), 12 / 48 (SDXL-UNet at 128 / 32 latents)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp8"],
                     help="bf16 (headline); fp8 = BASELINE config 5 (DiT block Linears on e4m3 / e5m2 operands, block-scaled MFMA)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -194,6 +195,8 @@ def main():
     from uwudiff_amd.optim import FusedAdamW, cosine_lr
     from uwudiff_amd.scheduler import EulerDiscreteScheduler
 
+    if args.batch is None:  # SDXL-UNet: ~12 GB of saved activations per 4x128x128 sample; 12 is 30.7 img/s, 6 is 24.8, 24 does not fit
+        args.batch = DEFAULT_BATCH if args.model != "SDXL-UNet" else (12 if args.latent == 128 else 48)
     B = args.batch
     torch.manual_seed(1215 + rank)  # configs/demo_training_latent.yaml:1 + test_train.py:69 (seed + rank)
     # random (non-zero) weights everywhere: zero-initialised gates would make whole branches numerically dead
