@@ -1048,8 +1048,9 @@ __global__ void __launch_bounds__(512, 2) gemm_wide_kernel(const GemmArgs g) {
 
 // ---- 64x128 tile for small token counts (a 128x128 grid that would leave most CUs idle) ---------------------------
 // Per-GPU batch 16 (the reference yaml) is M = 4096 rows: 32 x 3 = 96 tiles of 128x128 for an N = 384 Linear on 256
-// CUs.  Half-height tiles double the workgroups; 4 waves of 32 x 64 (FI = 2, FJ = 4), K-step 64, two LDS-DMA stages of
+// CUs.  Half-height tiles double the workgroups; 4 waves of 32 x 64 (FI = 2, FJ = 4), K-step 64, three LDS-DMA stages of
 // 24 KB.  Operand images as in gemm_kernel's LDS-DMA path (TB = 0) / gemm_r3_kernel's transposing reads (TB = 1).
+constexpr int M64_NST = 3;
 template <typename TC, int EPI, bool TB>
 __global__ void __launch_bounds__(256, 2) gemm_m64_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1089,7 +1090,7 @@ __global__ void __launch_bounds__(256, 2) gemm_m64_kernel(const GemmArgs g) {
     }
   }
   auto issue = [&](int s) {
-    char* st = smem + (s & 1) * STAGE;
+    char* st = smem + (s % M64_NST) * STAGE;
 #pragma unroll
     for (int q = 0; q < 2; ++q)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[q] + 64 * s),
@@ -1116,12 +1117,15 @@ __global__ void __launch_bounds__(256, 2) gemm_m64_kernel(const GemmArgs g) {
   EpiPre<T, 2, 4> pre;
   epi_prefetch<T, 2, 4, EPI>(pre, g, m0 + wm * 32, n0 + wn * 64, fr, fq);
 
+  // 3-stage ring, two K-steps in flight (6 DMA instructions per wave and stage, counted waits).  With one step in flight
+  // a K-step cost a whole load latency (~0.9 us: the fc1 input gradient at batch 16, K = 1536, took 22 us).
   issue(0);
+  if (nk > 1) issue(1);
   for (int s = 0; s < nk; ++s) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stage s landed (this wave's pieces)
-    __builtin_amdgcn_s_barrier();                     // ... everybody's; everybody is done reading stage s - 1
-    if (s + 1 < nk) issue(s + 1);
-    const char* la = smem + (s & 1) * STAGE;
+    if (s + 1 < nk) r_wait_vm<6>(); else r_wait_vm<0>();  // stage s landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();                         // ... everybody's; everybody is done reading stage s - 1
+    if (s + 2 < nk) issue(s + 2);
+    const char* la = smem + (s % M64_NST) * STAGE;
     const char* lb = la + A_BYTES;
     uint4 af[2][2], bf[2][4];
 #pragma unroll
@@ -1132,7 +1136,7 @@ __global__ void __launch_bounds__(256, 2) gemm_m64_kernel(const GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) bf[kk][j] = lds_read128_asm(lb + swz(wn * 64 + 16 * j + fr, 4 * kk + fq));
       } else {
-        const unsigned sb = smem_base + (unsigned)((s & 1) * STAGE + kk * R_BSUB);
+        const unsigned sb = smem_base + (unsigned)((s % M64_NST) * STAGE + kk * R_BSUB);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const uint2 lo = t_read_tr<0>(sb + (b_t0 ^ (unsigned)(j << 5)));
@@ -1756,7 +1760,12 @@ int launch_big(GemmArgs g, hipStream_t st) {
 template <typename TC, int EPI, bool TB>
 int launch_m64(GemmArgs g, hipStream_t st) {
   auto kern = gemm_m64_kernel<TC, EPI, TB>;
-  constexpr int LDS = 2 * (64 * ROW_BYTES + TILE_BYTES);
+  constexpr int LDS = M64_NST * (64 * ROW_BYTES + TILE_BYTES);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_done = true;
+  }
   g.tiles_m = (g.M + 63) / 64;
   g.tiles_n = (g.N + 127) / 128;
   UwuProfScope prof(st);

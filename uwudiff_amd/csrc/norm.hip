@@ -106,14 +106,14 @@ __global__ void __launch_bounds__(256) add_ln_mod_fwd_kernel(const T* __restrict
 // One workgroup = ROWS consecutive rows of ONE sample (T_tok % ROWS == 0); the 4 waves split the rows, keep the
 // per-column partial sums for dshift/dscale/dgate in registers, fold them through LDS and issue one fp32 atomic
 // per column per workgroup.
-template <typename T, int MAX_IT>
-__global__ void __launch_bounds__(256) add_ln_mod_bwd_kernel(
+template <typename T, int MAX_IT, int NW = 4>
+__global__ void __launch_bounds__(64 * NW) add_ln_mod_bwd_kernel(
     const T* __restrict__ dh, const T* __restrict__ x, const float* __restrict__ mean_i,
     const float* __restrict__ rstd_i, const float* __restrict__ scale, const T* __restrict__ dx_in,
     const T* __restrict__ y, const float* __restrict__ gate, int mod_ld, T* __restrict__ dx_out, T* __restrict__ dy,
     float* __restrict__ dshift, float* __restrict__ dscale, float* __restrict__ dgate, int M, int T_tok, int D,
     int rows_per_block, int affine) {
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][3][D]
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [NW waves][3][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nit = (D + 511) >> 9;
   const int row0 = blockIdx.x * rows_per_block;
@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(256) add_ln_mod_bwd_kernel(
 #pragma unroll
   for (int it = 0; it < MAX_IT; ++it) a_sh[it] = a_sc[it] = a_g[it] = f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-  for (int r = wave; r < rows_per_block; r += 4) {
+  for (int r = wave; r < rows_per_block; r += NW) {
     const int row = row0 + r;
     if (row >= M) break;
     const int64_t off = (int64_t)row * D;
@@ -184,8 +184,10 @@ __global__ void __launch_bounds__(256) add_ln_mod_bwd_kernel(
   }
   __syncthreads();
   const int ncol = (y ? 3 : 2) * D;
-  for (int c = threadIdx.x; c < ncol; c += 256) {
-    float t = red[c] + red[3 * D + c] + red[6 * D + c] + red[9 * D + c];
+  for (int c = threadIdx.x; c < ncol; c += 64 * NW) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t += red[w * 3 * D + c];
     const int which = c / D, d = c - which * D;
     float* dst = which == 0 ? dshift : (which == 1 ? dscale : dgate);
     if (dst) atomicAdd(dst + (int64_t)b * mod_ld + d, t);
@@ -338,6 +340,15 @@ extern "C" int uwu_add_ln_modulate_fwd(const void* x_in, const void* y, const fl
   return UWU_OK;
 }
 
+static bool small_ln_on() {  // UWU_LN_SMALL=0: the 4-wave kernel at every size (A/B comparisons)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("UWU_LN_SMALL");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v == 1;
+}
+
 extern "C" int uwu_add_ln_modulate_bwd(const void* dh, const void* x, const float* mean, const float* rstd,
                                        const float* scale, const void* dx_in, const void* y, const float* gate,
                                        int mod_ld, void* dx_out, void* dy, float* dshift, float* dscale, float* dgate,
@@ -410,7 +421,11 @@ extern "C" int uwu_add_ln_modulate_bwd(const void* dh, const void* x, const floa
   while (rows > 1 && T % rows) rows >>= 1;
   // small batches: fewer rows per workgroup (down to one per wave) until the grid has ~4 workgroups per CU -- at
   // M = 4096 the 128 workgroups of 32 rows took 18.5 us, most of it eight dependent row passes per wave
-  while (rows > 4 && M / rows < 1024) rows >>= 1;
+  // ... but every workgroup adds its column sums to the sample's 3 D floats: at M = 4096 the 1024 workgroups of 4 rows issued
+  // 1.2 M global atomics (13 us for 19 MB).  Small batches: 8 waves x 2 rows per workgroup, a quarter of the atomics.
+  const bool small = M / rows < 1024 && T % 16 == 0 && D <= 640 && small_ln_on();  // (8 x 3 x D floats of LDS <= 64 KB)
+  if (small) rows = 16;
+  while (!small && rows > 4 && M / rows < 1024) rows >>= 1;
   {
     static int forced = -1;
     if (forced < 0) {
@@ -419,7 +434,24 @@ extern "C" int uwu_add_ln_modulate_bwd(const void* dh, const void* x, const floa
     }
     if (forced > 0 && T % forced == 0) rows = forced;
   }
-  const size_t lds = (size_t)4 * 3 * D * sizeof(float);
+  const size_t lds = (size_t)(small ? 8 : 4) * 3 * D * sizeof(float);
+  if (small) {
+    UwuProfScope prof(stream);
+#define SMALL_CASE(NIT)                                                                                                \
+  case NIT:                                                                                                            \
+    hipLaunchKernelGGL((add_ln_mod_bwd_kernel<bf16_t, NIT, 8>), dim3(M / rows), dim3(512), lds, st, (const bf16_t*)dh, \
+                       (const bf16_t*)x, mean, rstd, scale, (const bf16_t*)dx_in, (const bf16_t*)y, gate, mod_ld,      \
+                       (bf16_t*)dx_out, (bf16_t*)dy, dshift, dscale, dgate, M, T, D, rows, affine);                    \
+    break;
+    if (dtype == UWU_BF16) {
+      switch ((D + 511) / 512) { SMALL_CASE(1) SMALL_CASE(2) }
+#undef SMALL_CASE
+      const double md = (double)M * D;
+      prof.done(UWU_PROF_LN_BWD, 0, 16.0 * md, md * 2.0 * (3 + (dx_in ? 1 : 0) + (y ? 2 : 0)));
+      UWU_LAUNCH_CHECK("add_ln_modulate_bwd");
+      return UWU_OK;
+    }
+  }
   UWU_CHECK_ARG(lds <= 160 * 1024, "add_ln_modulate_bwd: D=%d needs %zu B of LDS (> 160 KB)", D, lds);
   UwuProfScope prof(stream);
 #define BWD_CASE(NIT)                                                                                               \
