@@ -249,6 +249,19 @@ int uwu_prof_collect(int tag, int kind, double* ms, double* flops, double* bytes
 
 /* out[n] (+)= sum_m X[m,n]   (bias gradients). accumulate: 0 overwrite, 1 add. */
 int uwu_colsum(const void* X, int dtype, int M, int N, int ldx, float* out, int accumulate, void* stream);
+
+/* fp32 Linears with at most 64 rows (the conditioning path: timestep MLP, pooled-text projection, the adaLN modulation
+ * Linear of all blocks -- reference src/duwu/modules/rope_unet.py:306-309,393-411 run these as nn.Linear on [B, *]).
+ * Matrix-vector layouts that read / update the weight matrix once (csrc/skinny.hip).  uwu_skinny_linear_ok() says whether
+ * a shape is covered (M <= 64, X [M, K] fits LDS); dgrad additionally needs K <= 512.
+ *   fwd:   Y[M,N] = X[M,K] . W[N,K]^T (+ bias) ; epilogue UWU_EPI_NONE / _BIAS / _BIAS_SILU (Y2 = silu(Y))
+ *   dgrad: dX[M,K] = dY[M,N] . W[N,K]           (dX overwritten)
+ *   wgrad: dW[N,K] += dY^T . X ; db[N] += column sums of dY (db may be NULL) */
+int uwu_skinny_linear_ok(int M, int N, int K);
+int uwu_skinny_linear_fwd(const float* X, const float* W, const float* bias, float* Y, float* Y2, int M, int N, int K,
+                          int epilogue, void* stream);
+int uwu_skinny_linear_dgrad(const float* dY, const float* W, float* dX, int M, int N, int K, void* stream);
+int uwu_skinny_linear_wgrad(const float* dY, const float* X, float* dW, float* db, int M, int N, int K, void* stream);
 /* batched: out[b, n] (+)= sum_m X[b, m, n] for `batch` contiguous [M, ldx] slabs. */
 int uwu_colsum_batched(const void* X, int dtype, int batch, int M, int N, int ldx, float* out, int accumulate,
                        void* stream);

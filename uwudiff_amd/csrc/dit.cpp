@@ -178,6 +178,13 @@ int lin_fwd(const void* X, const void* W, const float* bias, void* Y, void* Y2, 
             int epi, void* st) {
   return uwu_gemm(X, W, Y, Y2, bias, nullptr, M, N, K, K, K, N, 0, 0, 0, dt, cdt, epi, 1, st);
 }
+// the fp32 conditioning Linears ([B, *] rows): matrix-vector kernels when the shape is covered (csrc/skinny.hip)
+int lin_fwd32(const float* X, const float* W, const float* bias, float* Y, float* Y2, int M, int N, int K, int epi, void* st) {
+  // measured at batch 16 (us, matrix-vector kernel vs 128x128-tile GEMM): 256 -> 384: 19 vs 25, 1280 -> 384: 22 vs 87; the
+  // adaLN Linear (N = 28416) 53 vs 33 -- its 64 wave reductions per 4 columns cost more than the tiles; 64 rows: slower throughout
+  if (M <= 16 && N <= 4096 && uwu_skinny_linear_ok(M, N, K)) return uwu_skinny_linear_fwd(X, W, bias, Y, Y2, M, N, K, epi, st);
+  return lin_fwd(X, W, bias, Y, Y2, M, N, K, UWU_F32, UWU_F32, epi, st);
+}
 // dX[M,K] = dY[M,N] . W[N,K]   (optionally * gelu'(aux[M,K]), then colsum[K] += column sums of dX)
 int lin_dgrad(const void* dY, const void* W, void* dX, const void* aux, int M, int N, int K, int dt, void* st,
               float* colsum = nullptr) {
@@ -221,6 +228,14 @@ int lin_wgrad(const void* dY, const void* X, float* dW, int M, int N, int K, int
   return uwu_gemm(dY, X, dW, nullptr, nullptr, nullptr, N, K, M, N, K, K, 0, 1, 1, dt, UWU_F32, UWU_EPI_ACCUM, split, st);
 }
 
+
+// dW += dY^T X and db += colsum(dY) of an fp32 conditioning Linear
+int lin_wgrad32(const float* dY, const float* X, float* dW, float* db, int M, int N, int K, void* st) {
+  // batch 16: 13 us vs 28 + 5 (GEMM + column sums) for the 384-wide Linears, 57 vs 77 + 5 for the adaLN Linear
+  if (M <= 16 && uwu_skinny_linear_ok(M, N, K)) return uwu_skinny_linear_wgrad(dY, X, dW, db, M, N, K, st);
+  RUN(lin_wgrad(dY, X, dW, M, N, K, UWU_F32, st));
+  return uwu_colsum(dY, UWU_F32, M, N, N, db, 1, st);
+}
 
 // ---- fp8 Linears (BASELINE config 5) ----------------------------------------------------------------------------
 // Every operand of the block-scaled-MFMA GEMM is contraction-contiguous fp8, so each Linear quantises its input
@@ -402,20 +417,17 @@ extern "C" int uwu_dit_forward(const uwu_dit_desc* dp, const float* noisy, const
 
   // ---- conditioning path (fp32): c = MLP(sinusoid(t)) + proj(cond); mod = Linear(silu(c)) for ALL layers at once
   RUN(uwu_timestep_embedding(t, B, d.freq_dim, 10000.f, P.at(L.feat), UWU_F32, st));
-  RUN(lin_fwd(P.at(L.feat), w32 + d.off_t_w1, w32 + d.off_t_b1, P.at(L.t_pre), P.at(L.t_h), B, D, d.freq_dim, UWU_F32,
-              UWU_F32, UWU_EPI_BIAS_SILU, st));
-  RUN(lin_fwd(P.at(L.t_h), w32 + d.off_t_w2, w32 + d.off_t_b2, P.at(L.temb), nullptr, B, D, D, UWU_F32, UWU_F32,
-              UWU_EPI_BIAS, st));
+  RUN(lin_fwd32(P.at<float>(L.feat), w32 + d.off_t_w1, w32 + d.off_t_b1, P.at<float>(L.t_pre), P.at<float>(L.t_h), B, D,
+                d.freq_dim, UWU_EPI_BIAS_SILU, st));
+  RUN(lin_fwd32(P.at<float>(L.t_h), w32 + d.off_t_w2, w32 + d.off_t_b2, P.at<float>(L.temb), nullptr, B, D, D, UWU_EPI_BIAS, st));
   const void* cptr = P.at(L.temb);
   if (cond) {
-    RUN(lin_fwd(cond, w32 + d.off_y_w, w32 + d.off_y_b, P.at(L.yemb), nullptr, B, D, d.cond_dim, UWU_F32, UWU_F32,
-                UWU_EPI_BIAS, st));
+    RUN(lin_fwd32(cond, w32 + d.off_y_w, w32 + d.off_y_b, P.at<float>(L.yemb), nullptr, B, D, d.cond_dim, UWU_EPI_BIAS, st));
     RUN(uwu_add(P.at(L.temb), P.at(L.yemb), P.at(L.c), (int64_t)B * D, UWU_F32, st));
     cptr = P.at(L.c);
   }
   RUN(uwu_silu_fwd(cptr, P.at(L.sc), (int64_t)B * D, UWU_F32, st));
-  RUN(lin_fwd(P.at(L.sc), w32 + d.off_mod_w, w32 + d.off_mod_b, P.at(L.mod), nullptr, B, ML, D, UWU_F32, UWU_F32,
-              UWU_EPI_BIAS, st));
+  RUN(lin_fwd32(P.at<float>(L.sc), w32 + d.off_mod_w, w32 + d.off_mod_b, P.at<float>(L.mod), nullptr, B, ML, D, UWU_EPI_BIAS, st));
   const float* mod = P.at<float>(L.mod);
 
   // ---- fp8 mode: this step's weights as fp8 (W for the forward, W^T for the input gradients), scaled per tensor
@@ -643,20 +655,18 @@ extern "C" int uwu_dit_backward(const uwu_dit_desc* dp, const float* dout, void*
   RUN(uwu_colsum(P.at(L.dx), dt, M, D, D, g + d.off_patch_b, 1, st));
 
   // ---- conditioning path (fp32)
-  RUN(lin_wgrad(dmod, P.at(L.sc), g + d.off_mod_w, B, ML, D, UWU_F32, st));
-  RUN(uwu_colsum(dmod, UWU_F32, B, ML, ML, g + d.off_mod_b, 1, st));
-  RUN(lin_dgrad_splitk(dmod, w32 + d.off_mod_w, P.at<float>(L.dsc), B, ML, D, st));
+  RUN(lin_wgrad32(dmod, P.at<float>(L.sc), g + d.off_mod_w, g + d.off_mod_b, B, ML, D, st));
+  RUN(lin_dgrad_splitk(dmod, w32 + d.off_mod_w, P.at<float>(L.dsc), B, ML, D, st));  // (matrix-vector form: 99 us vs 40)
   const void* cptr = d.cond_dim > 0 ? P.at(L.c) : P.at(L.temb);
   RUN(uwu_silu_bwd(cptr, P.at(L.dsc), P.at(L.dc), (int64_t)B * D, UWU_F32, st));
   if (d.cond_dim > 0) {
     // cond is an input; its projection weights get dW += dc^T cond.  `cond` itself is re-read from the caller.
   }
-  RUN(lin_wgrad(P.at(L.dc), P.at(L.t_h), g + d.off_t_w2, B, D, D, UWU_F32, st));
-  RUN(uwu_colsum(P.at(L.dc), UWU_F32, B, D, D, g + d.off_t_b2, 1, st));
-  RUN(lin_dgrad(P.at(L.dc), w32 + d.off_t_w2, P.at(L.dth), nullptr, B, D, D, UWU_F32, st));
+  RUN(lin_wgrad32(P.at<float>(L.dc), P.at<float>(L.t_h), g + d.off_t_w2, g + d.off_t_b2, B, D, D, st));
+  if (B <= 16 && uwu_skinny_linear_ok(B, D, D) && D <= 512) RUN(uwu_skinny_linear_dgrad(P.at<float>(L.dc), w32 + d.off_t_w2, P.at<float>(L.dth), B, D, D, st));
+  else RUN(lin_dgrad(P.at(L.dc), w32 + d.off_t_w2, P.at(L.dth), nullptr, B, D, D, UWU_F32, st));
   RUN(uwu_silu_bwd(P.at(L.t_pre), P.at(L.dth), P.at(L.dtp), (int64_t)B * D, UWU_F32, st));
-  RUN(lin_wgrad(P.at(L.dtp), P.at(L.feat), g + d.off_t_w1, B, D, d.freq_dim, UWU_F32, st));
-  RUN(uwu_colsum(P.at(L.dtp), UWU_F32, B, D, D, g + d.off_t_b1, 1, st));
+  RUN(lin_wgrad32(P.at<float>(L.dtp), P.at<float>(L.feat), g + d.off_t_w1, g + d.off_t_b1, B, D, d.freq_dim, st));
   return UWU_OK;
 }
 
@@ -668,7 +678,5 @@ extern "C" int uwu_dit_backward_cond(const uwu_dit_desc* dp, const float* cond, 
   if (!cond || !d.g32) { uwu_set_error("dit_backward_cond: null tensor"); return UWU_EINVAL; }
   const Layout L = make_layout(d);
   Ptrs P{static_cast<char*>(d.ws), L};
-  RUN(lin_wgrad(P.at(L.dc), cond, d.g32 + d.off_y_w, d.B, d.D, d.cond_dim, UWU_F32, st));
-  RUN(uwu_colsum(P.at(L.dc), UWU_F32, d.B, d.D, d.D, d.g32 + d.off_y_b, 1, st));
-  return UWU_OK;
+  return lin_wgrad32(P.at<float>(L.dc), cond, d.g32 + d.off_y_w, d.g32 + d.off_y_b, d.B, d.D, d.cond_dim, st);
 }

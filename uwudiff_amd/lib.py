@@ -77,6 +77,10 @@ _SIGS = {
     "uwu_prof_collect": (c_int, [c_int, c_int, P, P, P, P]),
     "uwu_colsum": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, P]),
     "uwu_colsum_batched": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, P]),
+    "uwu_skinny_linear_ok": (c_int, [c_int, c_int, c_int]),
+    "uwu_skinny_linear_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "uwu_skinny_linear_dgrad": (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    "uwu_skinny_linear_wgrad": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     "uwu_add_ln_modulate_fwd": (c_int, [P, P, P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_float, c_int, c_int, P]),
     "uwu_add_ln_modulate_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "uwu_attention_fwd": (c_int, [P, P, P, P, P] + [c_int] * 9 + [c_float, c_int, P]),

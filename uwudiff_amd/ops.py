@@ -350,3 +350,34 @@ class _RopeAttentionFn(torch.autograd.Function):
 def rope_attention(qkv, pos, fh, fw, B, T, H, d):
     """qkv: packed projection [B*T, 3*H*d] (bf16); pos [T, 2] fp32 (shared by the batch); fh / fw [H, d/4] log-frequencies."""
     return _RopeAttentionFn.apply(qkv, pos, fh, fw, B, T, H, d)
+
+
+# ------------------------------------------------------------------------- fp32 Linears with <= 64 rows (conditioning path)
+def skinny_linear_ok(M, N, K):
+    return bool(L.load().uwu_skinny_linear_ok(M, N, K))
+
+
+def skinny_linear_fwd(x, w, bias=None, epilogue=None):
+    """y = x w^T (+ bias); with epilogue L.EPI_BIAS_SILU returns (y, silu(y)).  fp32, x [M <= 64, K], w [N, K]."""
+    M, K = x.shape
+    N = w.shape[0]
+    epi = epilogue if epilogue is not None else (L.EPI_BIAS if bias is not None else L.EPI_NONE)
+    y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    y2 = torch.empty_like(y) if epi == L.EPI_BIAS_SILU else None
+    L.call("uwu_skinny_linear_fwd", L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(y), L.ptr(y2), M, N, K, epi, L.stream())
+    return (y, y2) if y2 is not None else y
+
+
+def skinny_linear_dgrad(dy, w):
+    M, N = dy.shape
+    K = w.shape[1]
+    dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
+    L.call("uwu_skinny_linear_dgrad", L.ptr(dy), L.ptr(w), L.ptr(dx), M, N, K, L.stream())
+    return dx
+
+
+def skinny_linear_wgrad(dy, x, dw, db=None):
+    M, N = dy.shape
+    K = x.shape[1]
+    L.call("uwu_skinny_linear_wgrad", L.ptr(dy), L.ptr(x), L.ptr(dw), L.ptr(db), M, N, K, L.stream())
+    return dw
