@@ -123,7 +123,7 @@ Layout make_layout(const uwu_dit_desc& d) {
       if (t > L.wsc_bytes) L.wsc_bytes = t;
   }
   L.wsc_bytes = (L.wsc_bytes + 255) & ~(size_t)255;
-  // forked backward (small batches): the four weight gradients of a block run on four streams, each with its own slices
+  // forked backward (small batches): the four weight gradients of a block may run on up to four streams, each with its own slices
   L.wsc = take(L.wsc_bytes * (L.M <= 16384 ? 4 : 1));
   if (d.fp8) {
     L.x8 = take(L.M * L.D4);
@@ -302,24 +302,31 @@ struct Fork {
   hipEvent_t ev[8];     // 0-3: producer done (recorded on main); 4-7: consumer done (recorded on side[slot])
   bool on = false;
 };
+unsigned fork_event_flags() {
+  const char* e = getenv("UWU_DIT_EVENT_SYSTEM");  // =1: default (system-scope) events, for A/B comparisons
+  return (e && e[0] == '1') ? hipEventDisableTiming : (hipEventDisableTiming | hipEventReleaseToDevice);
+}
 bool fork_resources(Fork& f, hipStream_t caller_side) {
   static hipEvent_t pool[8];
   static hipStream_t extra[3];
   static bool made = false;
   if (!made) {
     for (auto& e : pool)
-      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+      // device-scope release: these events only order streams of this GPU.  The default system-scope fence (cache writeback +
+      // invalidate so that the HOST could read the results) sat in front of every kernel that followed a record on the main stream
+      if (hipEventCreateWithFlags(&e, fork_event_flags()) != hipSuccess) return false;
     for (auto& x : extra)
       if (hipStreamCreateWithFlags(&x, hipStreamNonBlocking) != hipSuccess) return false;
     made = true;
   }
   for (int i = 0; i < 8; ++i) f.ev[i] = pool[i];
-  static int n_side = -1;  // UWU_DIT_SIDE_STREAMS=1: every weight gradient on the caller's side stream (A/B comparisons)
+  static int n_side = -1;  // UWU_DIT_SIDE_STREAMS=n (1..4): how many streams the four weight gradients of a block share
   if (n_side < 0) {
     const char* e = getenv("UWU_DIT_SIDE_STREAMS");
-    n_side = (e && e[0] == '1') ? 1 : 4;
+    n_side = e ? atoi(e) : 1;  // measured at batch 16 / 64 (img/s): 1: 4736 / 9606, 2: 4594 / 9548, 4: 4543 / 9512 -- with the
+    if (n_side < 1 || n_side > 4) n_side = 1;  // runtime's 4 hardware queues more streams only share queues (8 queues: 3x slower)
   }
-  for (int i = 0; i < 3; ++i) f.side[i] = n_side == 1 ? caller_side : extra[i];
+  for (int i = 0; i < 3; ++i) f.side[i] = n_side == 1 ? caller_side : extra[i % (n_side - 1)];
   f.side[3] = caller_side;
   return true;
 }
