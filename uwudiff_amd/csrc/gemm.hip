@@ -1781,7 +1781,12 @@ static bool use_m64(const GemmArgs& g, bool tb) {
   if (g.K % 64 || (((uintptr_t)g.A | (uintptr_t)g.B) & 15) || g.lda % 8 || g.ldb % 8) return false;
   if (tb && (g.N % 8 || g.N < 8)) return false;
   const int64_t tiles = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128);
-  return tiles < 256 && g.M > 64;
+  static int thr = -1;  // UWU_M64_TILES=n: sweeps
+  if (thr < 0) {
+    const char* t = getenv("UWU_M64_TILES");
+    thr = t ? atoi(t) : 256;
+  }
+  return tiles < thr && g.M > 64;
 }
 template <typename TC, int EPI, bool TB>
 int launch_wide(GemmArgs g, hipStream_t st) {
