@@ -2013,7 +2013,10 @@ int pick_r3(const GemmArgs& g, bool tb) {
     thr4 = e4 ? atoi(e4) : 128;
   }
   const int64_t t8 = (int64_t)((g.M + 255) / 256) * ((g.N + 127) / 128);
-  if (t8 >= thr8) return 8;
+  // long contractions (the UNet's K = 640 .. 5120): the larger tile's operand reuse pays from one workgroup per CU on
+  // (SDXL shape, 12 x 4x128x128: 480 tiles of 256x128 per 1280-wide Linear; 30.6 -> 31.8 images/s)
+  static const bool t8_env = getenv("UWU_R3_T8") != nullptr;
+  if (t8 >= ((g.K >= 640 && !t8_env) ? 256 : thr8)) return 8;
   const int64_t t4 = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128);
   return (tb && t4 >= thr4) ? 4 : 0;  // K-contiguous B at N = 384: gemm_kernel's 128-byte rows measured faster (proj 35 vs 43 us)
 }
