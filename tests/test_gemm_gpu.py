@@ -358,3 +358,38 @@ def test_gemm_r3_input_gradient_matches_128_kernel(M, N, K, monkeypatch):
     (d0, s0), (d1, s1) = _both(monkeypatch, run)
     assert torch.equal(d0, d1)
     torch.testing.assert_close(s0, s1, rtol=1e-3, atol=0.5)  # fp32 atomics: order differs
+
+
+# ---- many-tile weight gradients: the streaming kernel divides the 8 XCDs between K slices and tile lanes (1 slice from 320
+# tiles of 256x128 / 128x256 on, 2 from 140, 4 from 80; reductions of <= 1024 K-steps).  One slice writes C directly
+# (read-modify-write, no scratch), 2 / 4 go through the scratch + reduce kernel.  UWU_GEMM_TRW=0 keeps the 192x384 kernel
+# out of the way so that every shape exercises gemm_tr_kernel; exact on small integers, on top of existing C, with the fused
+# bias gradient, ragged last tiles and both tile orientations (tile lanes along m and along n).
+@pytest.mark.parametrize("M,N,K,slices", [
+    (10240, 1280, 2048, 1),   # 40 x 10 tiles of 256x128: lanes along m
+    (1280, 10240, 2048, 1),   # 10 x 40 tiles of 128x256: lanes along n
+    (5000, 2600, 2048, 1),    # ragged in both directions, 20 x 21 tiles
+    (3840, 1280, 2048, 2),    # 150 tiles
+    (1280, 5120, 4096, 2),    # 200 tiles of 128x256
+    (5120, 640, 4096, 4),     # 100 tiles
+    (2440, 1272, 2080, 4),    # 10 x 10 ragged tiles, K not a multiple of the slice length
+])
+def test_gemm_wgrad_many_tiles_xcd_partition(M, N, K, slices, monkeypatch):
+    from uwudiff_amd import lib as L
+    from uwudiff_amd import ops
+
+    monkeypatch.setenv("UWU_GEMM_TRW", "0")
+    a, b = _operands(M, N, K, True, True, torch.bfloat16, ints=True, seed=21)
+    want = a.float().t() @ b.float() + 2.0
+    bsum = a.float().sum(0) + 3.0
+    need = L.load().uwu_gemm_wgrad_scratch_bytes(M, N, K)
+    assert need >= slices * M * N * 4, (need, slices)  # (the size covers the other kernels' slice counts too)
+    dw = torch.full((M, N), 2.0, device="cuda")
+    db = torch.full((M,), 3.0, device="cuda")
+    ops.gemm_wgrad(a, b, dw, scratch=ops.gemm_wgrad_scratch(M, N, K), bias_grad=db)
+    assert torch.equal(dw, want)
+    assert torch.equal(db, bsum)
+    # without a scratch: one slice still writes directly, several fall back to 8 slice lanes + fp32 atomics (exact on integers)
+    dw = torch.full((M, N), 2.0, device="cuda")
+    ops.gemm_wgrad(a, b, dw, scratch=None)
+    assert torch.equal(dw, want)
