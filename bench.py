@@ -158,6 +158,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp8"],
                     help="bf16 (headline); fp8 = BASELINE config 5 (DiT block Linears on e4m3 / e5m2 operands, block-scaled MFMA)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--grad-checkpoint", action="store_true",
+                    help="SDXL-UNet: recompute resnets / Transformer2D stacks in the backward (larger batches fit)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the per-GPU batch sweep (16 / 64 / 256) after the timed region")
     ap.add_argument("--clip", type=float, default=0.0)
     ap.add_argument("--model", default=MODEL, choices=sorted(STEP_GFLOP),
@@ -205,6 +207,8 @@ def main():
         from uwudiff_amd.unet import UNet2DConditionModel
 
         model = UNet2DConditionModel.from_config("sdxl", compute_dtype=args.dtype).to(dev)
+        if args.grad_checkpoint:
+            model.enable_gradient_checkpointing()
     else:
         model = DiT.from_config(args.model, cond_dim=1280, init="random", compute_dtype=args.dtype).to(dev)
     if world > 1:  # identical replicas: broadcast rank 0's parameters

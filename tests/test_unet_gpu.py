@@ -119,3 +119,37 @@ def test_unet_in_diffusion_loss_step():
     opt.step()
     assert torch.isfinite(loss) and aux.pred.shape == x.shape
     assert (m.flat.data - p0).abs().max().item() > 0
+
+
+def test_unet_gradient_checkpointing_same_gradients_less_memory():
+    """enable_gradient_checkpointing() (reference test_scripts/test_train.py:38-39): resnets and Transformer2D stacks are
+    recomputed in the backward.  Output and parameter gradients agree with the plain path to within its own run-to-run
+    noise (fp32 atomics in the GroupNorm statistics and bias gradients), with a fraction of the saved activations."""
+    from tests.test_configs_gpu import unet_inputs, unet_models
+
+    _, model = unet_models("bf16", seed=5)
+    i = unet_inputs(2, 64, seed=6)
+    mv = lambda v: v.cuda()  # noqa: E731
+
+    def run(ckpt):
+        model.enable_gradient_checkpointing(ckpt)
+        model.flat.grad = torch.zeros_like(model.flat.data)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        y = model(mv(i["x"]), mv(i["t"]), encoder_hidden_states=mv(i["ctx"]),
+                  added_cond_kwargs={"text_embeds": mv(i["pooled"]), "time_ids": mv(i["ids"])})[0]
+        held = torch.cuda.memory_allocated() - base  # what the graph keeps alive for the backward
+        y.backward(mv(i["dout"]))
+        torch.cuda.synchronize()
+        return y.detach().clone(), model.flat.grad.clone(), held
+
+    y0, g0, held0 = run(False)
+    ya, ga, _ = run(False)  # run-to-run noise of the plain path (GroupNorm statistics are summed with fp32 atomics)
+    y1, g1, held1 = run(True)
+    model.enable_gradient_checkpointing(False)
+    noise_y, noise_g = rel(ya, y0)[0], ((ga - g0).norm() / g0.norm()).item()
+    assert rel(y1, y0)[0] <= max(2 * noise_y, 1e-3), (rel(y1, y0), noise_y)
+    err = ((g1 - g0).norm() / g0.norm()).item()
+    assert err <= max(3 * noise_g, 1e-3), (err, noise_g)
+    assert held1 < 0.25 * held0, (held0, held1)

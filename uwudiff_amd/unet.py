@@ -82,6 +82,10 @@ class _Ctx:
         self._held.append((done, operands))
         while self._held and self._held[0][0].query():
             self._held.popleft()
+        # back-pressure: the main stream never waits for the side stream inside the backward, so at large batches the weight
+        # gradients fall behind and their operands pile up (batch 48 with recomputation ran out of 288 GB this way)
+        while len(self._held) > 16:
+            self._held.popleft()[0].synchronize()
         if not self._join_queued:
             self._join_queued = True
             torch.autograd.Variable._execution_engine.queue_callback(self._join)
@@ -645,8 +649,18 @@ class UNet2DConditionModel(nn.Module):
         self.refresh_shadow()
         return r
 
-    def enable_gradient_checkpointing(self):
-        return None
+    def enable_gradient_checkpointing(self, enable=True):
+        """test_scripts/test_train.py:38-39.  Every resnet and every Transformer2D stack becomes one recomputed segment: only
+        segment inputs stay resident (≈ 1 GB instead of ≈ 12 GB of saved activations per 4x128x128 sample at the SDXL
+        shape) for one extra forward per segment.  Off by default: batch 12 fits 288 GB without it and runs 1/3 faster."""
+        self._ckpt = bool(enable)
+
+    def _seg(self, fn, *args):
+        if getattr(self, "_ckpt", False) and torch.is_grad_enabled():
+            from torch.utils.checkpoint import checkpoint
+
+            return checkpoint(fn, *args, use_reentrant=False, preserve_rng_state=False)
+        return fn(*args)
 
     # ------------------------------------------------------------------ blocks
     def _ones(self, n, dev):
@@ -768,27 +782,27 @@ class UNet2DConditionModel(nn.Module):
         h, w = H, W
         for blk in self.plan_down:
             for j, (n, cin, cout) in enumerate(blk["res"]):
-                x = self._resnet(x, emb_act, n, cin, cout, B, h, w)
+                x = self._seg(self._resnet, x, emb_act, n, cin, cout, B, h, w)
                 if blk["attn"]:
                     a, depth = blk["attn"][j]
-                    x = self._t2d(x, ctx, a, depth, blk["heads"], B, h * w, cout, Tk)
+                    x = self._seg(self._t2d, x, ctx, a, depth, blk["heads"], B, h * w, cout, Tk)
                 skips.append((x, cout))
             if blk["down"]:
                 x = self._conv(x, blk["down"], B, h, w, blk["ch"], stride=2)
                 h, w = (h + 1) // 2, (w + 1) // 2
                 skips.append((x, blk["ch"]))
         mid = boc[-1]
-        x = self._resnet(x, emb_act, "mid_block.resnets.0", mid, mid, B, h, w)
-        x = self._t2d(x, ctx, "mid_block.attentions.0", self.mid_depth, self.mid_heads, B, h * w, mid, Tk)
-        x = self._resnet(x, emb_act, "mid_block.resnets.1", mid, mid, B, h, w)
+        x = self._seg(self._resnet, x, emb_act, "mid_block.resnets.0", mid, mid, B, h, w)
+        x = self._seg(self._t2d, x, ctx, "mid_block.attentions.0", self.mid_depth, self.mid_heads, B, h * w, mid, Tk)
+        x = self._seg(self._resnet, x, emb_act, "mid_block.resnets.1", mid, mid, B, h, w)
         for blk in self.plan_up:
             for j, (n, rin, cout) in enumerate(blk["res"]):
                 s, sc = skips.pop()
                 x = torch.cat([x, s], dim=1)  # channel concat of token-major tensors (data movement only)
-                x = self._resnet(x, emb_act, n, rin, cout, B, h, w)
+                x = self._seg(self._resnet, x, emb_act, n, rin, cout, B, h, w)
                 if blk["attn"]:
                     a, depth = blk["attn"][j]
-                    x = self._t2d(x, ctx, a, depth, blk["heads"], B, h * w, cout, Tk)
+                    x = self._seg(self._t2d, x, ctx, a, depth, blk["heads"], B, h * w, cout, Tk)
             if blk["up"]:
                 x = _UpsampleFn.apply(x, B, h, w, blk["ch"])
                 h, w = 2 * h, 2 * w
