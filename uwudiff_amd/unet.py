@@ -746,6 +746,10 @@ class UNet2DConditionModel(nn.Module):
             self.flat.grad = torch.zeros_like(self.flat.data)
         if P.side is None and os.environ.get("UWU_UNET_FORK", "1") != "0":
             P.side = torch.cuda.Stream(device=dev)
+        if P.side is not None and torch.is_grad_enabled():
+            # a backward that raised between its first weight gradient and the engine's final callback never joined
+            torch.cuda.current_stream(dev).wait_stream(P.side)
+            P._join_queued = False
         if not torch.is_tensor(timestep):
             timestep = torch.tensor([timestep], device=dev)
         t = timestep.to(dev).float().reshape(-1).expand(B).contiguous()
