@@ -393,3 +393,28 @@ def test_gemm_wgrad_many_tiles_xcd_partition(M, N, K, slices, monkeypatch):
     dw = torch.full((M, N), 2.0, device="cuda")
     ops.gemm_wgrad(a, b, dw, scratch=None)
     assert torch.equal(dw, want)
+
+
+# ---- A-stationary kernel (gemm_as_kernel: K = 384, whole 256-row panels, N in 1024..2048): same MFMA sequence per output as
+# the 256x256 kernel it replaces for fc1 + bias + GELU, so both outputs must agree bit for bit (UWU_GEMM_AS=0 = the old path).
+@pytest.mark.parametrize("M,N", [(65536, 1536), (256, 1024), (196608, 1536), (1024, 2048)])
+def test_gemm_as_bias_gelu_matches_big_kernel(M, N, monkeypatch):
+    from uwudiff_amd import lib as L
+    from uwudiff_amd import ops
+
+    K = 384
+    a, b = _operands(M, N, K, False, False, torch.bfloat16, ints=False, seed=31)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(32)).cuda()
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("UWU_GEMM_AS", flag)
+        u = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        h = torch.empty_like(u)
+        for _ in range(3):  # the chunk pipeline must not depend on timing
+            ops.gemm(a, b, bias=bias, epilogue=L.EPI_BIAS_GELU, out=u, out2=h)
+        outs[flag] = (u.clone(), h.clone())
+    assert torch.equal(outs["1"][0], outs["0"][0])
+    assert torch.equal(outs["1"][1], outs["0"][1])
+    rows = slice(0, min(M, 2048))  # and against fp64 on a slice
+    want = a[rows].double() @ b.double().t() + bias.double()
+    assert (outs["1"][0][rows].double() - want).abs().max() <= 2e-2 * want.abs().max()

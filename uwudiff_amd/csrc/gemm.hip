@@ -1574,6 +1574,138 @@ __global__ void __launch_bounds__(512, 2) gemm_trw_kernel(const GemmArgs g) {
   }
 }
 
+// ---- A-stationary Linear for K = 384 with a store-heavy epilogue (fc1 + bias + GELU: 1208 MB out for 151 MB in) -------------
+// In gemm_big_kernel a tile's K loop and its store phase follow each other (one workgroup per CU, whose LDS is not released
+// before the stores are acknowledged): 438 us = ~190 us of loop + ~230 us of drain at the chip's write rate.  Here a workgroup
+// owns 256 rows for its whole life and walks the N columns in chunks of 64:
+//   * A (32 rows x 384 per wave) is loaded ONCE, straight into the MFMA fragment registers (96 VGPRs) -- it never touches LDS;
+//   * W chunks [64 n][384 k] (48 KB) stream through three LDS stages by LDS-DMA; a chunk's 12 K-steps run without a barrier;
+//   * the chunk's epilogue (bias from an LDS copy, GELU, two paired 16-byte stores per fragment pair) issues its 8 store
+//     instructions and moves on: vector-memory operations retire in issue order, the next chunk's DMA was issued BEFORE these
+//     stores, so `s_waitcnt vmcnt(8)` waits for the DMA alone and the stores drain under the next chunk's MFMAs.
+// Every wave reads the whole W chunk from LDS (8-fold): LDS and MFMA time are equal (3072 clocks per chunk), the stores need
+// 64 KB per chunk per CU -- the kernel is bound by the chip's write rate, not by the sum of the phases.
+constexpr int AS_K = 384, AS_BN = 64, AS_STAGE = AS_BN * AS_K * 2;  // 48 KB per W chunk
+constexpr int AS_NST = 3;
+constexpr int AS_LDS = AS_NST * AS_STAGE + 8192;                    // + the bias vector (<= 2048 columns) as fp32
+template <typename TC, int EPI>
+__global__ void __launch_bounds__(512, 2) gemm_as_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef bf16_t T;
+  constexpr int FI = 2, FJ = 4, KS = AS_K / 32;  // wave tile 32 rows x 64 columns; 12 K-steps of 32
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int m0 = blockIdx.x * 256 + wave * 32;
+  const T* A = static_cast<const T*>(g.A);
+  const T* B = static_cast<const T*>(g.B);
+  float* bias_lds = reinterpret_cast<float*>(smem + AS_NST * AS_STAGE);
+  if (EPI != UWU_EPI_NONE)
+    for (int n = tid; n < g.N; n += 512) bias_lds[n] = g.bias[n];
+
+  // A fragments: lane (fr, fq) holds A[m0 + 16 i + fr][32 s + 8 fq .. + 7]
+  uint4 af[FI][KS];
+#pragma unroll
+  for (int i = 0; i < FI; ++i)
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+      af[i][s] = *reinterpret_cast<const uint4*>(A + (int64_t)(m0 + 16 * i + fr) * g.lda + 32 * s + 8 * fq);
+
+  // W chunk DMA: piece q of wave w = 64-column K block q (8 KB sub-image, swizzled rows of 128 B), rows 8 w .. 8 w + 7
+  const int drow = 8 * wave + (lane >> 3);
+  const int dc = ((lane & 7) ^ (drow >> 1) ^ (drow >> 4)) & 7;
+  const T* bsrc = B + (int64_t)drow * g.ldb + 8 * dc;
+  const unsigned smem_base = (unsigned)(size_t)((const __attribute__((address_space(3))) char*)smem);
+  auto issue = [&](int c) {
+    const T* p = bsrc + (int64_t)c * AS_BN * g.ldb;
+#pragma unroll
+    for (int q = 0; q < AS_K / 64; ++q)  // (asm DMA: hipcc must not see it, or it drains vmcnt(0) in front of every LDS read)
+      glds16_asm(p + 64 * q, smem_base + (unsigned)((c % AS_NST) * AS_STAGE + q * 8192 + wave * 1024));
+  };
+  const int nchunks = g.N / AS_BN;
+  // Three stages, the DMA runs two chunks ahead.  The epilogue of chunk c - 1 (bias, GELU, rounding, lane exchange, stores:
+  // VALU + vector-memory work) is cut into four units and issued BETWEEN the K-steps of chunk c, whose MFMAs run in the matrix
+  // pipe meanwhile: with a whole-chunk epilogue after the K loop all eight waves sat in the same phase between the per-chunk
+  // barriers (231 us of K loops + 237 us of epilogues, nothing overlapped).  In issue order a wave has, at the top of chunk c:
+  //   .. DMA(c) | stores(c-3) | DMA(c+1) | stores(c-2)      (NS = 8 store instructions and 6 DMA instructions per chunk)
+  // and needs DMA(c): everything younger may stay in flight -> vmcnt(2 NS + 6).
+  static_assert(EPI == UWU_EPI_BIAS_GELU, "the interleaved epilogue is the bias + GELU one");
+  constexpr int NS = 8;
+  TC* const C = static_cast<TC*>(g.C);
+  TC* const C2 = static_cast<TC*>(g.C2);
+  const bool odd = fq & 1;
+  auto pack = [](const f32x4& v) {
+    bf16x4 b = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    return *reinterpret_cast<uint2*>(&b);
+  };
+  // one unit = row block i, fragment pair jp of the chunk at columns n0: 8 consecutive columns per lane after the exchange
+  auto epi_unit = [&](const f32x4 (&pa)[FI][FJ], int n0, int i, int jp) {
+    const float* bl = bias_lds + n0 + 32 * jp + 4 * fq;
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bl), b1 = *reinterpret_cast<const f32x4*>(bl + 16);
+    const f32x4 v0 = pa[i][2 * jp] + b0, v1 = pa[i][2 * jp + 1] + b1;
+    const f32x4 s0 = gelu_tanh_f4(v0), s1 = gelu_tanh_f4(v1);
+    const int m = m0 + 16 * i + fr;
+    const int n = n0 + 32 * jp + (odd ? 16 + 4 * (fq - 1) : 4 * fq);
+    typedef unsigned su32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned su32x4 __attribute__((ext_vector_type(4)));
+    auto exchange_store = [&](TC* dst, const f32x4& x0, const f32x4& x1, bool stream_out) {
+      const uint2 p0 = pack(x0), p1 = pack(x1);
+      const su32x2 sx = __builtin_amdgcn_permlane16_swap(p0.x, p1.x, false, false);
+      const su32x2 sy = __builtin_amdgcn_permlane16_swap(p0.y, p1.y, false, false);
+      const su32x4 o = su32x4{sx[0], sy[0], sx[1], sy[1]};
+      su32x4* ptr = reinterpret_cast<su32x4*>(dst + (int64_t)m * g.ldc + n);
+      if (stream_out) __builtin_nontemporal_store(o, ptr);
+      else *ptr = o;
+    };
+    exchange_store(C, v0, v1, true);   // pre-activation: only read again in the backward pass
+    exchange_store(C2, s0, s1, false);
+  };
+  f32x4 prev[FI][FJ];
+#pragma unroll
+  for (int i = 0; i < FI; ++i)
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) prev[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  issue(0);
+  issue(1);
+  for (int c = 0; c < nchunks; ++c) {
+    if (c == 0) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");  // DMA(1) may fly; this thread's bias words are in LDS
+    else if (c <= 2 || c + 1 >= nchunks) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // head / tail of the sequence
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NS + 6) : "memory");
+    __builtin_amdgcn_s_barrier();  // chunk c landed for everybody; everybody is done reading the stage of chunk c - 1
+    if (c + 2 < nchunks) issue(c + 2);
+    const char* lb = smem + (c % AS_NST) * AS_STAGE;
+    f32x4 acc[FI][FJ];
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+      for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // fragments of K-step s + 1 are requested before the MFMAs of step s (two register sets): with one wave in the matrix
+    // pipe per SIMD at a time nothing else hides the LDS latency
+    uint4 bf[2][FJ];
+    auto frags = [&](uint4 (&dst)[FJ], int s) {
+#pragma unroll
+      for (int j = 0; j < FJ; ++j)
+        dst[j] = *reinterpret_cast<const uint4*>(lb + (s >> 1) * 8192 + swz(16 * j + fr, 4 * (s & 1) + fq));
+    };
+    frags(bf[0], 0);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      if (s + 1 < KS) frags(bf[(s + 1) & 1], s + 1);
+#pragma unroll
+      for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) mma_frag<T>(bf[s & 1][j], af[i][s], acc[i][j]);
+      if (s % 3 == 1 && c > 0) epi_unit(prev, (c - 1) * AS_BN, (s / 3) >> 1, (s / 3) & 1);  // units after K-steps 1, 4, 7, 10
+    }
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+      for (int j = 0; j < FJ; ++j) prev[i][j] = acc[i][j];
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) epi_unit(prev, (nchunks - 1) * AS_BN, u >> 1, u & 1);
+}
+
 // ---- fp8 (OCP e4m3 / e5m2) operands on the block-scaled MFMA: BASELINE config 5 ("fp8 MFMA GEMMs") -----------------------
 // v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (E8M0 = 127) runs at twice the bf16 rate (MI355X_MICROARCH.md,
 // Matrix cores) -- the non-scaled fp8 MFMAs only reach the bf16 rate.  ONE kernel shape serves forward, input gradient and
@@ -1755,6 +1887,29 @@ int launch_big(GemmArgs g, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(512), LDS, st, g);
   prof.done(gemm_tag(g, TB, false), 0, 2.0 * g.M * g.N * g.K, gemm_bytes(g, 2, sizeof(TC)));
   UWU_LAUNCH_CHECK("gemm_big");
+  return UWU_OK;
+}
+// A-stationary kernel: K = 384, whole 256-row panels, 64-column chunks, bf16 output with the paired 16-byte stores.
+// UWU_GEMM_AS=0 turns it off (A/B comparisons).
+static bool use_as(const GemmArgs& g, int out_bytes) {
+  const char* e = getenv("UWU_GEMM_AS");
+  if (e && e[0] == '0') return false;
+  return g.K == AS_K && g.M % 256 == 0 && g.N % AS_BN == 0 && g.N <= 2048 && g.N >= 1024 && out_bytes == 2 && g.lda % 8 == 0 &&
+         g.ldb % 8 == 0 && g.ldc % 8 == 0 && (((uintptr_t)g.A | (uintptr_t)g.B | (uintptr_t)g.C | (uintptr_t)g.C2) & 15) == 0;
+}
+template <typename TC, int EPI>
+int launch_as(GemmArgs g, hipStream_t st) {
+  auto kern = gemm_as_kernel<TC, EPI>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, AS_LDS);
+    attr_done = true;
+  }
+  g.wide = 1;  // paired 16-byte stores
+  UwuProfScope prof(st);
+  hipLaunchKernelGGL(kern, dim3(g.M / 256), dim3(512), AS_LDS, st, g);
+  prof.done(gemm_tag(g, false, false), 0, 2.0 * g.M * g.N * g.K, gemm_bytes(g, 2, sizeof(TC)));
+  UWU_LAUNCH_CHECK("gemm_as");
   return UWU_OK;
 }
 template <typename TC, int EPI, bool TB>
@@ -2060,6 +2215,7 @@ int dispatch_trans(const GemmArgs& g, int ta, int tb, bool acc, int split, hipSt
             if (g.epi == UWU_EPI_NONE) return launch_wide<TC, UWU_EPI_NONE, false>(g, st);
             if (g.epi == UWU_EPI_BIAS) return launch_wide<TC, UWU_EPI_BIAS, false>(g, st);
           }
+          if (g.epi == UWU_EPI_BIAS_GELU && use_as(g, sizeof(TC))) return launch_as<TC, UWU_EPI_BIAS_GELU>(g, st);
           if (use_big(g)) {
             if (g.epi == UWU_EPI_BIAS_GELU) return launch_big<TC, UWU_EPI_BIAS_GELU, false>(g, st);
             if (g.epi == UWU_EPI_NONE) return launch_big<TC, UWU_EPI_NONE, false>(g, st);
