@@ -418,3 +418,22 @@ def test_gemm_as_bias_gelu_matches_big_kernel(M, N, monkeypatch):
     rows = slice(0, min(M, 2048))  # and against fp64 on a slice
     want = a[rows].double() @ b.double().t() + bias.double()
     assert (outs["1"][0][rows].double() - want).abs().max() <= 2e-2 * want.abs().max()
+
+
+@pytest.mark.parametrize("M,N", [(65536, 1152), (512, 1024), (196608, 1152)])
+def test_gemm_as_bias_matches_other_kernels(M, N, monkeypatch):
+    """the same kernel with the plain bias epilogue (qkv forward) against the 192x384 / 256x256 kernels: bit for bit."""
+    from uwudiff_amd import lib as L
+    from uwudiff_amd import ops
+
+    K = 384
+    a, b = _operands(M, N, K, False, False, torch.bfloat16, ints=False, seed=33)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(34)).cuda()
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("UWU_GEMM_AS_BIAS", flag)
+        y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        for _ in range(3):
+            ops.gemm(a, b, bias=bias, epilogue=L.EPI_BIAS, out=y)
+        outs[flag] = y.clone()
+    assert torch.equal(outs["1"], outs["0"])

@@ -1629,8 +1629,8 @@ __global__ void __launch_bounds__(512, 2) gemm_as_kernel(const GemmArgs g) {
   // barriers (231 us of K loops + 237 us of epilogues, nothing overlapped).  In issue order a wave has, at the top of chunk c:
   //   .. DMA(c) | stores(c-3) | DMA(c+1) | stores(c-2)      (NS = 8 store instructions and 6 DMA instructions per chunk)
   // and needs DMA(c): everything younger may stay in flight -> vmcnt(2 NS + 6).
-  static_assert(EPI == UWU_EPI_BIAS_GELU, "the interleaved epilogue is the bias + GELU one");
-  constexpr int NS = 8;
+  static_assert(EPI == UWU_EPI_BIAS_GELU || EPI == UWU_EPI_BIAS, "the interleaved epilogue: bias (+ GELU)");
+  constexpr int NS = EPI == UWU_EPI_BIAS_GELU ? 8 : 4;
   TC* const C = static_cast<TC*>(g.C);
   TC* const C2 = static_cast<TC*>(g.C2);
   const bool odd = fq & 1;
@@ -1643,7 +1643,6 @@ __global__ void __launch_bounds__(512, 2) gemm_as_kernel(const GemmArgs g) {
     const float* bl = bias_lds + n0 + 32 * jp + 4 * fq;
     const f32x4 b0 = *reinterpret_cast<const f32x4*>(bl), b1 = *reinterpret_cast<const f32x4*>(bl + 16);
     const f32x4 v0 = pa[i][2 * jp] + b0, v1 = pa[i][2 * jp + 1] + b1;
-    const f32x4 s0 = gelu_tanh_f4(v0), s1 = gelu_tanh_f4(v1);
     const int m = m0 + 16 * i + fr;
     const int n = n0 + 32 * jp + (odd ? 16 + 4 * (fq - 1) : 4 * fq);
     typedef unsigned su32x2 __attribute__((ext_vector_type(2)));
@@ -1657,8 +1656,12 @@ __global__ void __launch_bounds__(512, 2) gemm_as_kernel(const GemmArgs g) {
       if (stream_out) __builtin_nontemporal_store(o, ptr);
       else *ptr = o;
     };
-    exchange_store(C, v0, v1, true);   // pre-activation: only read again in the backward pass
-    exchange_store(C2, s0, s1, false);
+    if constexpr (EPI == UWU_EPI_BIAS_GELU) {
+      exchange_store(C, v0, v1, true);  // pre-activation: only read again in the backward pass
+      exchange_store(C2, gelu_tanh_f4(v0), gelu_tanh_f4(v1), false);
+    } else {
+      exchange_store(C, v0, v1, false);
+    }
   };
   f32x4 prev[FI][FJ];
 #pragma unroll
@@ -1896,6 +1899,10 @@ static bool use_as(const GemmArgs& g, int out_bytes) {
   if (e && e[0] == '0') return false;
   return g.K == AS_K && g.M % 256 == 0 && g.N % AS_BN == 0 && g.N <= 2048 && g.N >= 1024 && out_bytes == 2 && g.lda % 8 == 0 &&
          g.ldb % 8 == 0 && g.ldc % 8 == 0 && (((uintptr_t)g.A | (uintptr_t)g.B | (uintptr_t)g.C | (uintptr_t)g.C2) & 15) == 0;
+}
+static bool use_as_bias() {  // the plain bias Linears with N >= 1024 (qkv forward: 285 -> 231 us in the step); UWU_GEMM_AS_BIAS=0: off
+  const char* e = getenv("UWU_GEMM_AS_BIAS");
+  return !(e && e[0] == '0');
 }
 template <typename TC, int EPI>
 int launch_as(GemmArgs g, hipStream_t st) {
@@ -2211,6 +2218,7 @@ int dispatch_trans(const GemmArgs& g, int ta, int tb, bool acc, int split, hipSt
       const int r3 = pick_r3(g, false);
       if (r3 == 8) {
         if constexpr (hot) {
+          if (g.epi == UWU_EPI_BIAS && use_as_bias() && use_as(g, sizeof(TC))) return launch_as<TC, UWU_EPI_BIAS>(g, st);
           if (use_wide(g)) {
             if (g.epi == UWU_EPI_NONE) return launch_wide<TC, UWU_EPI_NONE, false>(g, st);
             if (g.epi == UWU_EPI_BIAS) return launch_wide<TC, UWU_EPI_BIAS, false>(g, st);
