@@ -349,6 +349,8 @@ int uwu_silu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dtype, 
 
 /* out = a + b elementwise (same dtype). */
 int uwu_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream);
+/* dst[c][r] = src[r][c], bf16 (a weight matrix laid out contraction-contiguous for the input-gradient GEMM) */
+int uwu_transpose_bf16(const void* src, void* dst, int rows, int cols, int ld_src, int ld_dst, void* stream);
 
 /* patchify: latent [B,C,H,W] (fp32) -> tokens [B*(H/p)*(W/p), C*p*p] (dtype), feature order (c,ph,pw).
  * unpatchify is the inverse (tokens -> fp32 image).  Conv2d(k=p,s=p) patch embedding == patchify + GEMM. */

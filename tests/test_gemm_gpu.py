@@ -437,3 +437,26 @@ def test_gemm_as_bias_matches_other_kernels(M, N, monkeypatch):
             ops.gemm(a, b, bias=bias, epilogue=L.EPI_BIAS, out=y)
         outs[flag] = y.clone()
     assert torch.equal(outs["1"], outs["0"])
+
+
+@pytest.mark.parametrize("M,N", [(65536, 1536), (256, 1024), (196608, 1536)])
+def test_gemm_as_dgelu_matches_k_major_kernel(M, N):
+    """du = (dy . W2) * gelu'(u) through the A-stationary kernel on the TRANSPOSED weight (uwu_transpose_bf16) against the
+    256x256 kernel on the K-major weight: same MFMA sequence per output, bit for bit."""
+    from uwudiff_amd import lib as L
+    from uwudiff_amd import ops
+
+    K = 384
+    g = torch.Generator().manual_seed(41)
+    dy = (torch.randn(M, K, generator=g) * 0.1).bfloat16().cuda()
+    w2 = (torch.randn(K, N, generator=g) / K ** 0.5).bfloat16().cuda()   # [out = K, in = N]: K-major for this product
+    u = torch.randn(M, N, generator=g).bfloat16().cuda()
+    ref = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(dy, w2, trans_b=True, aux=u, epilogue=L.EPI_DGELU, out=ref)
+    w2t = torch.empty(N, K, device="cuda", dtype=torch.bfloat16)
+    L.call("uwu_transpose_bf16", L.ptr(w2), L.ptr(w2t), K, N, N, K, L.stream())
+    assert torch.equal(w2t, w2.t().contiguous())
+    got = torch.empty_like(ref)
+    for _ in range(3):
+        ops.gemm(dy, w2t, aux=u, epilogue=L.EPI_DGELU, out=got)
+    assert torch.equal(got, ref)

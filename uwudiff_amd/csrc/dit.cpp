@@ -35,6 +35,7 @@ struct Layout {
   size_t xF, mF, rF, hF, otok;
   // backward scratch
   size_t dx, dy, dh, dqkv, dao, du, delta, dotok, dmod, dsc, dc, dth, dtp;
+  size_t w2t;  // fc2 weight of the block in flight, transposed to [4D, D] (input gradient through the A-stationary kernel)
   size_t wsc, wsc_bytes;  // split-K scratch of the weight-gradient GEMMs
   // fp8 mode: quantised operand copies (reused by every Linear) and the per-layer fp8 weights (W and W^T)
   size_t x8, x8t, dy8, dy8t, w8, w8_layer;
@@ -104,6 +105,7 @@ Layout make_layout(const uwu_dit_desc& d) {
   L.dqkv = take(L.M * L.D3 * L.es);
   L.dao = take(L.M * L.D * L.es);
   L.du = take(L.M * L.D4 * L.es);
+  L.w2t = take((size_t)L.D4 * d.D * 2);
   L.delta = take((size_t)d.B * d.H * d.T * f4);
   L.dotok = take(L.M * L.Ko * L.es);
   L.dmod = take((size_t)d.B * d.mod_total * f4);
@@ -177,6 +179,14 @@ int check_desc(const uwu_dit_desc* d) {
 int lin_fwd(const void* X, const void* W, const float* bias, void* Y, void* Y2, int M, int N, int K, int dt, int cdt,
             int epi, void* st) {
   return uwu_gemm(X, W, Y, Y2, bias, nullptr, M, N, K, K, K, N, 0, 0, 0, dt, cdt, epi, 1, st);
+}
+static bool fc2_dgrad_as() {  // UWU_DIT_FC2DG_AS=0: the 256x256 kernel on the K-major weight (A/B comparisons)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("UWU_DIT_FC2DG_AS");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v == 1;
 }
 // the fp32 conditioning Linears ([B, *] rows): matrix-vector kernels when the shape is covered (csrc/skinny.hip)
 int lin_fwd32(const float* X, const float* W, const float* bias, float* Y, float* Y2, int M, int N, int K, int epi, void* st) {
@@ -578,7 +588,15 @@ extern "C" int uwu_dit_backward(const uwu_dit_desc* dp, const float* dout, void*
     if (side_used[1]) RUN(join_side(fk, 1));  // the previous block's fc1 weight gradient still reads du
     // du = (dy.W2) * gelu'(u).  The fc1 bias gradient = colsum(du) comes out of the fc1 weight-gradient kernel (extra MFMAs
     // against an all-ones fragment, free there) -- as fp32 atomics in this epilogue it cost 79 us per launch at B = 768
-    RUN(lin_dgrad(P.at(L.dy), w.fc2_w, P.at(L.du), P.lay(l, L.o_u), M, D, D4, dt, st, nullptr));
+    if (dt == UWU_BF16 && D == 384 && M % 256 == 0 && D4 % 64 == 0 && D4 >= 1024 && D4 <= 2048 && fc2_dgrad_as()) {
+      // the store-heavy input gradient (604 MB in, 604 MB out for 151 MB of dy): W2 transposed once (1.2 MB), then the
+      // A-stationary kernel with dy held in fragment registers and the dGELU epilogue between the K-steps
+      RUN(uwu_transpose_bf16(w.fc2_w, P.at(L.w2t), D, D4, D4, D, st));
+      RUN(uwu_gemm(P.at(L.dy), P.at(L.w2t), P.at(L.du), nullptr, nullptr, P.lay(l, L.o_u), M, D4, D, D, D, D4, D4, 0, 0, dt, dt,
+                   UWU_EPI_DGELU, 1, st));
+    } else {
+      RUN(lin_dgrad(P.at(L.dy), w.fc2_w, P.at(L.du), P.lay(l, L.o_u), M, D, D4, dt, st, nullptr));
+    }
     RUN(on_side(fk, 1, [&](void* s2, int k) {
       return lin_wgrad(P.at(L.du), P.lay(l, L.o_h2), g + w.off_fc1_w, M, D4, D, dt, s2, wsc + (size_t)k * L.wsc_bytes, L.wsc_bytes, g + w.off_fc1_b);
     }));

@@ -159,3 +159,33 @@ extern "C" int uwu_add(const void* a, const void* b, void* out, int64_t n, int d
   UWU_LAUNCH_CHECK("add");
   return UWU_OK;
 }
+
+// dst[c][r] = src[r][c] for a bf16 matrix (weights only: the input-gradient GEMM of a store-heavy Linear wants its weight
+// contraction-contiguous, csrc/gemm.hip gemm_as_kernel).  32 x 32 tiles through LDS, coalesced on both sides.
+namespace {
+__global__ void __launch_bounds__(256) transpose_bf16_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int rows,
+                                                             int cols, int lds, int ldd) {
+  __shared__ bf16_t tile[32][34];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + ty + 8 * k, c = c0 + tx;
+    tile[ty + 8 * k][tx] = (r < rows && c < cols) ? src[(int64_t)r * lds + c] : (bf16_t)0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + ty + 8 * k, r = r0 + tx;
+    if (c < cols && r < rows) dst[(int64_t)c * ldd + r] = tile[tx][ty + 8 * k];
+  }
+}
+}  // namespace
+
+extern "C" int uwu_transpose_bf16(const void* src, void* dst, int rows, int cols, int ld_src, int ld_dst, void* stream) {
+  UWU_CHECK_ARG(src && dst && rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= rows, "transpose_bf16: bad argument");
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)src, (bf16_t*)dst, rows, cols, ld_src, ld_dst);
+  UWU_LAUNCH_CHECK("transpose_bf16");
+  return UWU_OK;
+}

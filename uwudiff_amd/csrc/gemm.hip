@@ -1600,7 +1600,7 @@ __global__ void __launch_bounds__(512, 2) gemm_as_kernel(const GemmArgs g) {
   const T* A = static_cast<const T*>(g.A);
   const T* B = static_cast<const T*>(g.B);
   float* bias_lds = reinterpret_cast<float*>(smem + AS_NST * AS_STAGE);
-  if (EPI != UWU_EPI_NONE)
+  if (EPI == UWU_EPI_BIAS || EPI == UWU_EPI_BIAS_GELU)
     for (int n = tid; n < g.N; n += 512) bias_lds[n] = g.bias[n];
 
   // A fragments: lane (fr, fq) holds A[m0 + 16 i + fr][32 s + 8 fq .. + 7]
@@ -1629,8 +1629,9 @@ __global__ void __launch_bounds__(512, 2) gemm_as_kernel(const GemmArgs g) {
   // barriers (231 us of K loops + 237 us of epilogues, nothing overlapped).  In issue order a wave has, at the top of chunk c:
   //   .. DMA(c) | stores(c-3) | DMA(c+1) | stores(c-2)      (NS = 8 store instructions and 6 DMA instructions per chunk)
   // and needs DMA(c): everything younger may stay in flight -> vmcnt(2 NS + 6).
-  static_assert(EPI == UWU_EPI_BIAS_GELU || EPI == UWU_EPI_BIAS, "the interleaved epilogue: bias (+ GELU)");
-  constexpr int NS = EPI == UWU_EPI_BIAS_GELU ? 8 : 4;
+  static_assert(EPI == UWU_EPI_BIAS_GELU || EPI == UWU_EPI_BIAS || EPI == UWU_EPI_DGELU, "the interleaved epilogues");
+  // vector-memory instructions of one chunk's epilogue: 8 stores (two outputs), 4 stores, or 4 stores + 4 aux loads (dGELU)
+  constexpr int NS = EPI == UWU_EPI_BIAS ? 4 : 8;
   TC* const C = static_cast<TC*>(g.C);
   TC* const C2 = static_cast<TC*>(g.C2);
   const bool odd = fq & 1;
@@ -1639,14 +1640,34 @@ __global__ void __launch_bounds__(512, 2) gemm_as_kernel(const GemmArgs g) {
     return *reinterpret_cast<uint2*>(&b);
   };
   // one unit = row block i, fragment pair jp of the chunk at columns n0: 8 consecutive columns per lane after the exchange
+  // dGELU: the pre-activation tile of unit u (8 consecutive columns per lane, the layout of the paired stores) is loaded right
+  // after the unit of the previous chunk has consumed its registers -- a whole chunk period before it is needed
+  uint4 auxr[4];
+  const T* const auxp = static_cast<const T*>(g.aux);
+  auto aux_load = [&](int n0, int u) {
+    const int i = u >> 1, jp = u & 1;
+    const int m = m0 + 16 * i + fr, n = n0 + 32 * jp + (odd ? 16 + 4 * (fq - 1) : 4 * fq);
+    auxr[u] = *reinterpret_cast<const uint4*>(auxp + (int64_t)m * g.ldaux + n);
+  };
   auto epi_unit = [&](const f32x4 (&pa)[FI][FJ], int n0, int i, int jp) {
-    const float* bl = bias_lds + n0 + 32 * jp + 4 * fq;
-    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bl), b1 = *reinterpret_cast<const f32x4*>(bl + 16);
-    const f32x4 v0 = pa[i][2 * jp] + b0, v1 = pa[i][2 * jp + 1] + b1;
-    const int m = m0 + 16 * i + fr;
-    const int n = n0 + 32 * jp + (odd ? 16 + 4 * (fq - 1) : 4 * fq);
+    f32x4 v0 = pa[i][2 * jp], v1 = pa[i][2 * jp + 1];
     typedef unsigned su32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned su32x4 __attribute__((ext_vector_type(4)));
+    if constexpr (EPI == UWU_EPI_DGELU) {
+      const uint4 a = auxr[2 * i + jp];  // un-swap: this lane's own 4 columns of both fragments
+      const su32x2 sx = __builtin_amdgcn_permlane16_swap(a.x, a.z, false, false);
+      const su32x2 sy = __builtin_amdgcn_permlane16_swap(a.y, a.w, false, false);
+      const uint2 r0 = {sx[0], sy[0]}, r1 = {sx[1], sy[1]};
+      const bf16x4 u0 = *reinterpret_cast<const bf16x4*>(&r0), u1 = *reinterpret_cast<const bf16x4*>(&r1);
+      v0 = v0 * dgelu_tanh_f4(f32x4{(float)u0[0], (float)u0[1], (float)u0[2], (float)u0[3]});
+      v1 = v1 * dgelu_tanh_f4(f32x4{(float)u1[0], (float)u1[1], (float)u1[2], (float)u1[3]});
+    } else {
+      const float* bl = bias_lds + n0 + 32 * jp + 4 * fq;
+      v0 = v0 + *reinterpret_cast<const f32x4*>(bl);
+      v1 = v1 + *reinterpret_cast<const f32x4*>(bl + 16);
+    }
+    const int m = m0 + 16 * i + fr;
+    const int n = n0 + 32 * jp + (odd ? 16 + 4 * (fq - 1) : 4 * fq);
     auto exchange_store = [&](TC* dst, const f32x4& x0, const f32x4& x1, bool stream_out) {
       const uint2 p0 = pack(x0), p1 = pack(x1);
       const su32x2 sx = __builtin_amdgcn_permlane16_swap(p0.x, p1.x, false, false);
@@ -1684,21 +1705,31 @@ __global__ void __launch_bounds__(512, 2) gemm_as_kernel(const GemmArgs g) {
       for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // fragments of K-step s + 1 are requested before the MFMAs of step s (two register sets): with one wave in the matrix
     // pipe per SIMD at a time nothing else hides the LDS latency
-    uint4 bf[2][FJ];
+    // (the dGELU variant has no registers for the second set: one spilled register would put scratch accesses into the counted
+    // vmcnt sequence)
+    constexpr int NBF = EPI == UWU_EPI_DGELU ? 1 : 2;
+    uint4 bf[NBF][FJ];
     auto frags = [&](uint4 (&dst)[FJ], int s) {
 #pragma unroll
       for (int j = 0; j < FJ; ++j)
         dst[j] = *reinterpret_cast<const uint4*>(lb + (s >> 1) * 8192 + swz(16 * j + fr, 4 * (s & 1) + fq));
     };
-    frags(bf[0], 0);
+    if constexpr (NBF == 2) frags(bf[0], 0);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      if (s + 1 < KS) frags(bf[(s + 1) & 1], s + 1);
+      if constexpr (NBF == 2) {
+        if (s + 1 < KS) frags(bf[(s + 1) & 1], s + 1);
+      } else {
+        frags(bf[0], s);
+      }
 #pragma unroll
       for (int i = 0; i < FI; ++i)
 #pragma unroll
-        for (int j = 0; j < FJ; ++j) mma_frag<T>(bf[s & 1][j], af[i][s], acc[i][j]);
-      if (s % 3 == 1 && c > 0) epi_unit(prev, (c - 1) * AS_BN, (s / 3) >> 1, (s / 3) & 1);  // units after K-steps 1, 4, 7, 10
+        for (int j = 0; j < FJ; ++j) mma_frag<T>(bf[s & (NBF - 1)][j], af[i][s], acc[i][j]);
+      if (s % 3 == 1) {  // units after K-steps 1, 4, 7, 10
+        if (c > 0) epi_unit(prev, (c - 1) * AS_BN, (s / 3) >> 1, (s / 3) & 1);
+        if constexpr (EPI == UWU_EPI_DGELU) aux_load(c * AS_BN, s / 3);
+      }
     }
 #pragma unroll
     for (int i = 0; i < FI; ++i)
@@ -2224,6 +2255,9 @@ int dispatch_trans(const GemmArgs& g, int ta, int tb, bool acc, int split, hipSt
             if (g.epi == UWU_EPI_BIAS) return launch_wide<TC, UWU_EPI_BIAS, false>(g, st);
           }
           if (g.epi == UWU_EPI_BIAS_GELU && use_as(g, sizeof(TC))) return launch_as<TC, UWU_EPI_BIAS_GELU>(g, st);
+          if (g.epi == UWU_EPI_DGELU && g.C2 == nullptr && g.aux && g.ldaux % 8 == 0 && ((uintptr_t)g.aux & 15) == 0 &&
+              use_as(g, sizeof(TC)))
+            return launch_as<TC, UWU_EPI_DGELU>(g, st);
           if (use_big(g)) {
             if (g.epi == UWU_EPI_BIAS_GELU) return launch_big<TC, UWU_EPI_BIAS_GELU, false>(g, st);
             if (g.epi == UWU_EPI_NONE) return launch_big<TC, UWU_EPI_NONE, false>(g, st);

@@ -97,6 +97,7 @@ _SIGS = {
     "uwu_silu_fwd": (c_int, [P, P, c_int64, c_int, P]),
     "uwu_silu_bwd": (c_int, [P, P, P, c_int64, c_int, P]),
     "uwu_add": (c_int, [P, P, P, c_int64, c_int, P]),
+    "uwu_transpose_bf16": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "uwu_patchify": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "uwu_unpatchify": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     "uwu_add_pos": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
