@@ -62,3 +62,45 @@ def test_ctypes_arity_matches_header():
         params = protos[name].strip()
         n = 0 if params in ("", "void") else params.count(",") + 1
         assert n == len(args), f"{name}: header has {n} params, ctypes table has {len(args)}"
+
+
+def test_counted_vmcnt_kernels_do_not_spill(tmp_path):
+    """gemm_as_kernel hand-counts its vector-memory operations (s_waitcnt vmcnt(N)); a register spill would add scratch
+    accesses to that sequence.  Checked on the kernel metadata of the built library's gfx950 code objects (no GPU needed)."""
+    import os
+    import re
+    import subprocess
+
+    import pytest
+
+    from uwudiff_amd import build
+
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")]
+    if not all(os.path.exists(t) for t in tools):
+        pytest.skip("LLVM binary utilities not available")
+    if not os.path.exists(build.LIB):
+        build.build()
+    fat = tmp_path / "fat.bin"
+    subprocess.run([tools[0], f"--dump-section=.hip_fatbin={fat}", build.LIB, str(tmp_path / "unused.so")], check=True,
+                   capture_output=True)
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    blob = fat.read_bytes()
+    starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+    assert starts, "no offload bundles in the library"
+    seen = 0
+    for i, st in enumerate(starts):  # one bundle per translation unit
+        part = tmp_path / f"bundle{i}.bin"
+        part.write_bytes(blob[st:starts[i + 1] if i + 1 < len(starts) else len(blob)])
+        co = tmp_path / f"co{i}.o"
+        subprocess.run([tools[1], "--unbundle", "--type=o", f"--input={part}", f"--output={co}",
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950"], capture_output=True)
+        if not co.exists() or co.stat().st_size == 0:
+            continue
+        notes = subprocess.run([tools[2], "--notes", str(co)], capture_output=True, text=True).stdout
+        for m in re.finditer(r"\.name:\s+(\S*gemm_as_kernel\S*)", notes):
+            seen += 1
+            tail = notes[m.end():m.end() + 1500]
+            sp = re.search(r"\.vgpr_spill_count:\s*(\d+)", tail)
+            assert sp and int(sp.group(1)) == 0, (m.group(1), tail[:300])
+    assert seen >= 3, seen

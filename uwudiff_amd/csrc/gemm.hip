@@ -1928,7 +1928,12 @@ int launch_big(GemmArgs g, hipStream_t st) {
 static bool use_as(const GemmArgs& g, int out_bytes) {
   const char* e = getenv("UWU_GEMM_AS");
   if (e && e[0] == '0') return false;
-  return g.K == AS_K && g.M % 256 == 0 && g.N % AS_BN == 0 && g.N <= 2048 && g.N >= 1024 && out_bytes == 2 && g.lda % 8 == 0 &&
+  static int nmin = -1;  // UWU_AS_NMIN=n: sweeps
+  if (nmin < 0) {
+    const char* t = getenv("UWU_AS_NMIN");
+    nmin = t ? atoi(t) : 1024;
+  }
+  return g.K == AS_K && g.M % 256 == 0 && g.N % AS_BN == 0 && g.N <= 2048 && g.N >= nmin && out_bytes == 2 && g.lda % 8 == 0 &&
          g.ldb % 8 == 0 && g.ldc % 8 == 0 && (((uintptr_t)g.A | (uintptr_t)g.B | (uintptr_t)g.C | (uintptr_t)g.C2) & 15) == 0;
 }
 static bool use_as_bias() {  // the plain bias Linears with N >= 1024 (qkv forward: 285 -> 231 us in the step); UWU_GEMM_AS_BIAS=0: off
