@@ -397,7 +397,7 @@ def test_gemm_wgrad_many_tiles_xcd_partition(M, N, K, slices, monkeypatch):
 
 # ---- A-stationary kernel (gemm_as_kernel: K = 384, whole 256-row panels, N in 1024..2048): same MFMA sequence per output as
 # the 256x256 kernel it replaces for fc1 + bias + GELU, so both outputs must agree bit for bit (UWU_GEMM_AS=0 = the old path).
-@pytest.mark.parametrize("M,N", [(65536, 1536), (256, 1024), (196608, 1536), (1024, 2048)])
+@pytest.mark.parametrize("M,N", [(65536, 1536), (65536, 1024), (196608, 1536), (65536, 2048), (1024, 2048)])
 def test_gemm_as_bias_gelu_matches_big_kernel(M, N, monkeypatch):
     from uwudiff_amd import lib as L
     from uwudiff_amd import ops
@@ -420,7 +420,7 @@ def test_gemm_as_bias_gelu_matches_big_kernel(M, N, monkeypatch):
     assert (outs["1"][0][rows].double() - want).abs().max() <= 2e-2 * want.abs().max()
 
 
-@pytest.mark.parametrize("M,N", [(65536, 1152), (512, 1024), (196608, 1152)])
+@pytest.mark.parametrize("M,N", [(65536, 1152), (65536, 1024), (196608, 1152), (512, 1024)])
 def test_gemm_as_bias_matches_other_kernels(M, N, monkeypatch):
     """the same kernel with the plain bias epilogue (qkv forward) against the 192x384 / 256x256 kernels: bit for bit."""
     from uwudiff_amd import lib as L
@@ -439,7 +439,7 @@ def test_gemm_as_bias_matches_other_kernels(M, N, monkeypatch):
     assert torch.equal(outs["1"], outs["0"])
 
 
-@pytest.mark.parametrize("M,N", [(65536, 1536), (256, 1024), (196608, 1536)])
+@pytest.mark.parametrize("M,N", [(65536, 1536), (65536, 1024), (196608, 1536), (256, 1024)])
 def test_gemm_as_dgelu_matches_k_major_kernel(M, N):
     """du = (dy . W2) * gelu'(u) through the A-stationary kernel on the TRANSPOSED weight (uwu_transpose_bf16) against the
     256x256 kernel on the K-major weight: same MFMA sequence per output, bit for bit."""

@@ -588,7 +588,7 @@ extern "C" int uwu_dit_backward(const uwu_dit_desc* dp, const float* dout, void*
     if (side_used[1]) RUN(join_side(fk, 1));  // the previous block's fc1 weight gradient still reads du
     // du = (dy.W2) * gelu'(u).  The fc1 bias gradient = colsum(du) comes out of the fc1 weight-gradient kernel (extra MFMAs
     // against an all-ones fragment, free there) -- as fp32 atomics in this epilogue it cost 79 us per launch at B = 768
-    if (dt == UWU_BF16 && D == 384 && M % 256 == 0 && D4 % 64 == 0 && D4 >= 1024 && D4 <= 2048 && fc2_dgrad_as()) {
+    if (dt == UWU_BF16 && D == 384 && M % 256 == 0 && M >= 256 * 256 && D4 % 64 == 0 && D4 >= 1024 && D4 <= 2048 && fc2_dgrad_as()) {
       // the store-heavy input gradient (604 MB in, 604 MB out for 151 MB of dy): W2 transposed once (1.2 MB), then the
       // A-stationary kernel with dy held in fragment registers and the dGELU epilogue between the K-steps
       RUN(uwu_transpose_bf16(w.fc2_w, P.at(L.w2t), D, D4, D4, D, st));

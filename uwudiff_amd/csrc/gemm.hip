@@ -1933,7 +1933,9 @@ static bool use_as(const GemmArgs& g, int out_bytes) {
     const char* t = getenv("UWU_AS_NMIN");
     nmin = t ? atoi(t) : 1024;
   }
-  return g.K == AS_K && g.M % 256 == 0 && g.N % AS_BN == 0 && g.N <= 2048 && g.N >= nmin && out_bytes == 2 && g.lda % 8 == 0 &&
+  // one workgroup per 256 rows: below one per CU the chip is under-filled (per-GPU batch 64: 9.8k -> 8.2k images/s with it)
+  return g.K == AS_K && g.M % 256 == 0 && g.M >= 256 * 256 && g.N % AS_BN == 0 && g.N <= 2048 && g.N >= nmin && out_bytes == 2 &&
+         g.lda % 8 == 0 &&
          g.ldb % 8 == 0 && g.ldc % 8 == 0 && (((uintptr_t)g.A | (uintptr_t)g.B | (uintptr_t)g.C | (uintptr_t)g.C2) & 15) == 0;
 }
 static bool use_as_bias() {  // the plain bias Linears with N >= 1024 (qkv forward: 285 -> 231 us in the step); UWU_GEMM_AS_BIAS=0: off
