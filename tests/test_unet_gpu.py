@@ -149,7 +149,7 @@ def test_unet_gradient_checkpointing_same_gradients_less_memory():
     y1, g1, held1 = run(True)
     model.enable_gradient_checkpointing(False)
     noise_y, noise_g = rel(ya, y0)[0], ((ga - g0).norm() / g0.norm()).item()
-    assert rel(y1, y0)[0] <= max(2 * noise_y, 1e-3), (rel(y1, y0), noise_y)
+    assert rel(y1, y0)[0] <= max(3 * noise_y, 5e-3), (rel(y1, y0), noise_y)  # (bf16: one ulp is 4e-3)
     err = ((g1 - g0).norm() / g0.norm()).item()
-    assert err <= max(3 * noise_g, 1e-3), (err, noise_g)
+    assert err <= max(3 * noise_g, 5e-3), (err, noise_g)
     assert held1 < 0.25 * held0, (held0, held1)
