@@ -545,6 +545,37 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_mfma(const MArgs a) {
     if (t + 1 < nt) store_tile((t + 1) & 1);
     __syncthreads();  // dS image free again; next stage visible
   }
+  if constexpr (DQ && DH == 64) {
+    // One-kernel variant (T <= 256): the accumulators hold 4 consecutive d of one key per lane -- stored directly that is 16
+    // contiguous bytes per row and instruction, eight partial writes per 128-byte dK / dV row.  Every wave passes its
+    // [32 keys][64 d] tiles through its own 8 KB of the (now idle) LDS and stores whole rows: 8 lanes x 16 B per key.
+    if (ROPE || a.ldt != -99) {  // (non-RoPE launches: ldt = -99 switches back to the direct stores, UWU_ATTN_ROWSTORE=0)
+      char* mine = smem + wave * 8192;  // [2 tensors][32 keys][128 B]
+      if (active) {
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int d0 = 32 * dt + 8 * g4 + 4 * h;
+            store4(reinterpret_cast<bf16_t*>(mine + r * 128) + d0,
+                   f32x4{dkT[dt][4 * g4] * a.scale, dkT[dt][4 * g4 + 1] * a.scale, dkT[dt][4 * g4 + 2] * a.scale,
+                         dkT[dt][4 * g4 + 3] * a.scale});
+            store4(reinterpret_cast<bf16_t*>(mine + 4096 + r * 128) + d0,
+                   f32x4{dvT[dt][4 * g4], dvT[dt][4 * g4 + 1], dvT[dt][4 * g4 + 2], dvT[dt][4 * g4 + 3]});
+          }
+        // (same wave wrote and reads: no barrier; the compiler orders the LDS accesses)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int key = 8 * p + (lane >> 3), ch = lane & 7;
+          const uint4 kx = *reinterpret_cast<const uint4*>(mine + key * 128 + ch * 16);
+          const uint4 vx = *reinterpret_cast<const uint4*>(mine + 4096 + key * 128 + ch * 16);
+          *reinterpret_cast<uint4*>(a.dk + (int64_t)b * a.Tk * a.ldk + hd * DH + (int64_t)(k0 + key) * a.ldk + 8 * ch) = kx;
+          *reinterpret_cast<uint4*>(a.dv + (int64_t)b * a.Tk * a.ldv + hd * DH + (int64_t)(k0 + key) * a.ldv + 8 * ch) = vx;
+        }
+      }
+      return;
+    }
+  }
   if (active && kvalid) {
     bf16_t* dkb = a.dk + (int64_t)b * a.Tk * a.ldk + hd * DH + (int64_t)(k0 + r) * a.ldk;
     bf16_t* dvb = a.dv + (int64_t)b * a.Tk * a.ldv + hd * DH + (int64_t)(k0 + r) * a.ldv;
@@ -874,6 +905,14 @@ int uwu_attn_mfma_bwd(const void* q, const void* k, const void* v, const void* o
   a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
   a.kbias = kbias;
   a.B = B; a.T = T; a.Tk = Tk; a.H = H; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.scale = scale;
+  {
+    static int rowstore = -1;  // UWU_ATTN_ROWSTORE=0: direct 8-byte dK / dV stores (A/B comparisons)
+    if (rowstore < 0) {
+      const char* e = getenv("UWU_ATTN_ROWSTORE");
+      rowstore = (e && e[0] == '0') ? 0 : 1;
+    }
+    a.ldt = rowstore ? 0 : -99;
+  }
   if (d == 64) launch_bwd<64>(a, st);
   else if (d == 72) launch_bwd<72>(a, st);
   else launch_bwd<128>(a, st);
