@@ -96,6 +96,10 @@ def self_launch(n):
     port = s.getsockname()[1]
     s.close()
     procs = []
+    # HSA_ENABLE_IPC_MODE_LEGACY=0 (kept if the caller already set it): RCCL's intra-node transport over xGMI maps the peers'
+    # buffers through hipIpcGetMemHandle; this pool's host driver supports only the dmabuf IPC mode, and with the legacy mode
+    # that call fails ("invalid argument") before the first collective.  The image exports it already -- the default here
+    # only covers a shell that lost it.  It has no effect on gloo.
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
@@ -159,7 +163,13 @@ def main():
                     help="bf16 (headline); fp8 = BASELINE config 5 (DiT block Linears on e4m3 / e5m2 operands, block-scaled MFMA)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--grad-checkpoint", action="store_true",
-                    help="SDXL-UNet: recompute resnets / Transformer2D stacks in the backward (larger batches fit)")
+                    help="recompute in the backward (larger batches fit): DiT per transformer block inside the C++ driver, "
+                         "SDXL-UNet per resnet / Transformer2D stack")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the short runs of the other BASELINE configs (DiT-B/2, DiT-XL/2 fp8, SDXL-UNet 4x128x128) after the headline")
+    ap.add_argument("--single-allreduce", action="store_true",
+                    help="N > 1: ONE all-reduce of the whole flat gradient buffer after the backward (north_star's wording) instead "
+                         "of the overlapped block-group + chunked exchange -- A/B switch for the scaling run")
     ap.add_argument("--no-sweep", action="store_true", help="skip the per-GPU batch sweep (16 / 64 / 256) after the timed region")
     ap.add_argument("--clip", type=float, default=0.0)
     ap.add_argument("--model", default=MODEL, choices=sorted(STEP_GFLOP),
@@ -211,6 +221,8 @@ def main():
             model.enable_gradient_checkpointing()
     else:
         model = DiT.from_config(args.model, cond_dim=1280, init="random", compute_dtype=args.dtype).to(dev)
+        if args.grad_checkpoint:
+            model.enable_gradient_checkpointing()
     if world > 1:  # identical replicas: broadcast rank 0's parameters
         dist.broadcast(model.flat.data, src=0)
         if hasattr(model, "refresh_shadow"):
@@ -218,7 +230,8 @@ def main():
     loss_fn = DiffusionLoss(EulerDiscreteScheduler.from_pretrained("stabilityai/stable-diffusion-xl-base-1.0",
                                                                    subfolder="scheduler"))
     opt = FusedAdamW(model.parameters(), lr=1e-6, weight_decay=0.01, betas=(0.9, 0.999))
-    sync = FlatGradSync(world).attach(model)  # N > 1: block gradients are reduced while the backward still runs
+    # N > 1: block gradients are reduced while the backward still runs (--single-allreduce: one call after it)
+    sync = FlatGradSync(world, single=args.single_allreduce).attach(model)
     S = args.latent
     step_gflop = STEP_GFLOP[args.model][S] if unet else STEP_GFLOP[args.model]
     pool_n = max(4096 if S == 32 else 64, 2 * B)
@@ -299,7 +312,9 @@ def main():
             model.set_grad_ready_hook(None)
         nosync = FlatGradSync(1)
         t_nosync, _ = timed(n_c, sy=nosync)
-        comm = {"rccl_ranks": dist.get_world_size(), "backend": args.backend,
+        comm = {"rccl_ranks": dist.get_world_size(), "backend": args.backend, "exchange_path": sync.path,
+                "exchange": "one all-reduce after the backward" if args.single_allreduce else
+                            "block groups reduced inside the backward + the rest in 32 MB chunks, AdamW per reduced slice",
                 "ms_per_step_with_exchange": round(t_sync / n_c * 1e3, 3),
                 "ms_per_step_without_exchange": round(t_nosync / n_c * 1e3, 3),
                 "exposed_comm_ms": round((t_sync - t_nosync) / n_c * 1e3, 3),
@@ -329,13 +344,15 @@ def main():
             # same command, gfx950 corrections applied by tools/summarize_pmc.py).  The file names the kernel source
             # it was measured on; a number from other kernels is not reported.
             traffic, traffic_src = None, None
-            tj = os.path.join(ROOT, "profiles", "r02_pmc_gemm_traffic.json")
-            if args.dtype == "bf16" and B == DEFAULT_BATCH and args.model == MODEL and os.path.exists(tj):
-                with open(tj) as f:
-                    tjd = json.load(f)
-                if tjd.get("gemm_src_sha16") == src_sha16():
-                    traffic = round(tjd["hbm_bytes_per_launch"])
-                    traffic_src = "profiles/r02_pmc_gemm_traffic.json (separate --pmc passes over this command, same gemm.hip)"
+            for tjn in ("r03_pmc_gemm_traffic.json", "r02_pmc_gemm_traffic.json"):
+                tj = os.path.join(ROOT, "profiles", tjn)
+                if traffic is None and args.dtype == "bf16" and B == DEFAULT_BATCH and args.model == MODEL and os.path.exists(tj) \
+                        and not args.grad_checkpoint:
+                    with open(tj) as f:
+                        tjd = json.load(f)
+                    if tjd.get("gemm_src_sha16") == src_sha16():
+                        traffic = round(tjd["hbm_bytes_per_launch"])
+                        traffic_src = f"profiles/{tjn} (separate --pmc passes over this command, same gemm.hip)"
             fam = ("fp8 block-scaled MFMA GEMM family (gemm_f8_kernel, v_mfma_scale_f32_16x16x128_f8f6f4: fwd + dgrad + split-K wgrad of the "
                    "block Linears; the few Linears outside the blocks stay bf16)" if args.dtype == "fp8" else
                    "bf16 MFMA GEMM family (gemm_kernel / gemm_r3_kernel / gemm_big_kernel / gemm_wide_kernel / gemm_tr_kernel, "
@@ -367,6 +384,12 @@ def main():
             sweep[str(b)] = round(b * n_s / el, 1)
         sweep[str(B)] = round(B * args.steps / elapsed, 1)
 
+    # ---- the other BASELINE configs (configs[2..4]) under the same clock: short child runs of this same script, one at a
+    # time, after the headline's timed region (this process only waits; it keeps its 33 GB of HBM, the children fit beside it)
+    secondary = None
+    if rank == 0 and world == 1 and args.model == MODEL and args.dtype == "bf16" and not args.no_secondary:
+        secondary = run_secondary()
+
     if rank == 0:
         imgs = B * world * args.steps
         value = imgs / elapsed
@@ -387,6 +410,7 @@ def main():
             "roofline": roof,
             "batch_sweep": sweep,
             "comm": comm,
+            "secondary": secondary,
         }
         if not args.no_cpu_baseline and world == 1 and args.model == MODEL:
             line["cpu_baseline"] = cpu_baseline()
@@ -395,6 +419,33 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+SECONDARY = [  # BASELINE.json configs[2..4] at one GPU's share of the work (per-GPU batch as in profiles/)
+    ("DiT-B/2 bf16 (config 3)", ["--model", "DiT-B/2", "--batch", "256"]),
+    ("DiT-XL/2 fp8 (config 5)", ["--model", "DiT-XL/2", "--dtype", "fp8", "--batch", "192"]),
+    ("SDXL-UNet 4x128x128 bf16 (config 4)", ["--model", "SDXL-UNet", "--latent", "128", "--batch", "12"]),
+]
+
+
+def run_secondary(steps=5, warmup=2):
+    out = {}
+    for name, extra in SECONDARY:
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup),
+               "--no-cpu-baseline", "--no-sweep", "--no-secondary", *extra]
+        print(f"[bench] secondary: {name} ...", file=sys.stderr, flush=True)
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+            line = json.loads(r.stdout.strip().splitlines()[-1])
+            roof = line.get("roofline") or {}
+            out[name] = {"images_per_s": line["value"], "ms_per_step": line["ms_per_step"], "per_gpu_batch": line["config"]["per_gpu_batch"],
+                         "dtype": line["dtype"], "steps": steps, "warmup": warmup, "model_tflops": line["model_tflops"],
+                         "mfma_frac_whole_step": line["mfma_frac_whole_step"], "gemm_family_frac": roof.get("frac"),
+                         "final_loss": line["final_loss"], "wall_s": round(time.perf_counter() - t0, 1)}
+        except Exception as e:  # a failed child must not take the headline line down with it
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    return out
 
 
 def src_sha16():

@@ -51,6 +51,9 @@ extern "C" {
 
 const char* uwu_last_error(void);
 int uwu_version(void);
+/* The library's environment switches (UWU_GEMM_*, ...: kernel A/B comparisons and sweeps, tools/README.md) are read once
+ * and cached; call this after changing one inside a running process.  Returns the new generation number. */
+int uwu_env_refresh(void);
 
 /* ------------------------------------------------------------------ objective (a1-a10) */
 
@@ -426,6 +429,12 @@ typedef struct uwu_dit_desc {
   float* f8_scale;      /* [12 L] per-tensor quantisation scales */
   float* f8_amax;       /* [12 L] running max |x| of the current step */
   const int32_t* f8_fmt; /* [12 L] UWU_FP8_E4M3 / UWU_FP8_E5M2 per role */
+  /* block recomputation (the reference's enable_gradient_checkpointing, test_scripts/test_train.py:38-39; diffusers
+   * rope_unet.py:484-507 checkpoints per transformer block): != 0 keeps per block only its input x0 and the row statistics
+   * of its first LayerNorm; every other saved activation lives in ONE slab shared by all blocks, and uwu_dit_backward reruns
+   * block l - 1 from its kept input before it needs that block's tensors.  Workspace: L * (M*D + 8 M) + one full block slab
+   * instead of L full slabs.  Same kernels on the same inputs: the recomputed tensors are bit-identical. */
+  int32_t checkpoint;
 } uwu_dit_desc;
 
 size_t uwu_dit_workspace_bytes(const uwu_dit_desc* d);

@@ -23,3 +23,29 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture
+def monkeypatch(monkeypatch):
+    """libuwu_hip.so caches its environment switches (UWU_GEMM_* ...): re-read them after every change a test makes,
+    and once more after the changes are undone."""
+    def refresh():
+        from uwudiff_amd import lib
+
+        if os.path.exists(lib.LIB_PATH):
+            lib.load().uwu_env_refresh()
+
+    real_set, real_del = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv(*a, **k):
+        real_set(*a, **k)
+        refresh()
+
+    def delenv(*a, **k):
+        real_del(*a, **k)
+        refresh()
+
+    monkeypatch.setenv, monkeypatch.delenv = setenv, delenv
+    yield monkeypatch
+    monkeypatch.undo()
+    refresh()

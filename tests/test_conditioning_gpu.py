@@ -82,6 +82,54 @@ def test_vae_latent_normalisation_is_fused_into_qsample():
     torch.testing.assert_close(l2, l1, rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("kind", ["rf", "rf_rescale_image", "rf_rescale_noise", "nnw", "nnw_rescale_image", "rf_5d"])
+def test_vae_latent_normalisation_in_rf_and_nnw_losses(kind):
+    """Every loss sees the NORMALISED latent (reference trainer.py:241-244 normalises between the VAE and the loss), also
+    NNWeightedRFLoss, and with rescale_image the per-sample std is the normalised latent's (normalise first, then rescale)."""
+    from uwudiff_amd.objective import NNWeightedRFLoss, RectifiedFlowLoss
+    from uwudiff_amd.scheduler import EulerDiscreteScheduler
+
+    torch.manual_seed(1)
+    B = 4
+    x, noise = torch.randn(B, 4, 8, 8) * 3 + 1, torch.randn(B, 4, 8, 8)
+    u, out = torch.rand(B), torch.randn(B, 4, 8, 8)
+    mean, std = 0.7, 2.5
+
+    class Leaf(torch.nn.Module):
+        def forward(self, noisy, ts, **kw):
+            return (out.cuda(),)
+
+    class LossPred(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.tensor(0.3))
+
+        def forward(self, noisy, sigmas, **kw):
+            return self.w * noisy.flatten(1).mean(1) - 0.2 * sigmas.log()
+
+    def make():
+        kw = dict(scheduler=EulerDiscreteScheduler.from_pretrained("sdxl"), rescale_image="rescale_image" in kind,
+                  rescale_noise="rescale_noise" in kind)
+        if kind.startswith("nnw"):
+            torch.manual_seed(2)
+            return NNWeightedRFLoss(loss_pred_module=LossPred().cuda(), **kw)
+        return RectifiedFlowLoss(**kw)
+
+    plain, fused = make(), make()
+    fused.set_latent_normalisation(mean, std)
+    xin_plain, xin_fused = (x - mean) / std, x
+    if kind == "rf_5d":
+        xin_plain, xin_fused = torch.stack([xin_plain, noise], 1), torch.stack([x, noise], 1)
+    plain.inject(noise=noise.cuda(), u01=u.cuda())
+    l1, a1 = plain(xin_plain.cuda(), Leaf())  # what the reference does: normalise, then the loss
+    fused.inject(noise=noise.cuda(), u01=u.cuda())
+    l2, a2 = fused(xin_fused.cuda(), Leaf())
+    torch.testing.assert_close(a2.noisy_latent, a1.noisy_latent, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(a2.target, a1.target, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(a2.losses, a1.losses, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(l2, l1, rtol=1e-5, atol=1e-6)
+
+
 def test_trainer_vae_slot_encodes_and_normalises():
     from duwu.trainer import DMTrainer
 

@@ -171,3 +171,76 @@ def test_sdxl_width_unet_128_latents_properties():
     assert l2 < 2e-2, (l2, mx)  # bf16: split-K slice counts differ between the two batch sizes
     l2, mx = rel(model.flat.grad, full)
     assert l2 < 2e-2, (l2, mx)
+
+
+# ---------------------------------------------------------------------------------------------------- full depth
+def _full_depth_properties(model, make_inputs, B, steps=3, lr=2e-4, add_tol=2e-2):
+    """Size-independent properties at the FULL depth of a BASELINE config (the oracle comparisons above
+    cut the depth): finite loss and gradients, gradients additive over two half batches, and the eps-MSE loss decreasing
+    over `steps` AdamW steps on a fixed batch."""
+    from uwudiff_amd.optim import FusedAdamW
+
+    inp = make_inputs(B)
+
+    def loss_of(sl):
+        out = model(inp["x"][sl], inp["t"][sl], **{k: (v[sl] if torch.is_tensor(v) else {kk: vv[sl] for kk, vv in v.items()})
+                                                   for k, v in inp["kw"].items()})[0]
+        n = inp["x"][sl].shape[0]
+        return ((out - inp["eps"][sl]) ** 2).flatten(1).mean(1).sum() / B, n
+
+    model.flat.grad = torch.zeros_like(model.flat.data)
+    l_full, _ = loss_of(slice(0, B))
+    l_full.backward()
+    full = model.flat.grad.clone()
+    assert torch.isfinite(l_full) and torch.isfinite(full).all() and float(full.abs().max()) > 0
+    model.flat.grad.zero_()
+    for sl in (slice(0, B // 2), slice(B // 2, B)):
+        loss_of(sl)[0].backward()
+    l2, mx = rel(model.flat.grad, full)
+    assert l2 < add_tol, (l2, mx)
+    opt = FusedAdamW(model.parameters(), lr=lr, weight_decay=0.0)
+    losses = []
+    for _ in range(steps + 1):
+        model.flat.grad.zero_()
+        l, _ = loss_of(slice(0, B))
+        losses.append(float(l.detach()))
+        l.backward()
+        opt.step()
+    assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0], losses
+    return losses
+
+
+def _dit_inputs(B, seed=0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    r = lambda *s: torch.randn(*s, device="cuda", generator=g)  # noqa: E731
+    return dict(x=r(B, 4, 32, 32), t=torch.randint(0, 1000, (B,), device="cuda", generator=g).float(), eps=r(B, 4, 32, 32),
+                kw={"added_cond_kwargs": {"text_embeds": r(B, 1280)}})
+
+
+@pytest.mark.parametrize("preset,dtype,B", [("DiT-B/2", "bf16", 32), ("DiT-XL/2", "fp8", 32)], ids=["dit_b2_L12", "dit_xl2_L28_fp8"])
+def test_full_depth_dit_properties(preset, dtype, B):
+    from uwudiff_amd.dit import DiT
+
+    torch.manual_seed(17)
+    model = DiT.from_config(preset, cond_dim=1280, init="random", compute_dtype=dtype, fp8_scaling="jit").cuda()
+    assert model.cfg.depth == {"DiT-B/2": 12, "DiT-XL/2": 28}[preset]
+    # fp8: per-tensor scales are taken per call, so half batches quantise on slightly different grids
+    _full_depth_properties(model, _dit_inputs, B, add_tol=2e-2 if dtype == "bf16" else 8e-2)
+
+
+def test_full_depth_sdxl_unet_properties():
+    """The whole SDXL stack (transformer depth 1 / 2 / 10, 2.57 B parameters, 77 x 2048 context) at 4x32x32, batch 2."""
+    from uwudiff_amd.unet import UNet2DConditionModel
+
+    torch.manual_seed(19)
+    model = UNet2DConditionModel.from_config("sdxl", compute_dtype="bf16").cuda()
+    assert sum(v.numel() for _, v in model.state_dict().items()) == 2_567_463_684
+
+    def inputs(B):
+        g = torch.Generator(device="cuda").manual_seed(3)
+        r = lambda *s: torch.randn(*s, device="cuda", generator=g)  # noqa: E731
+        ids = torch.tensor([[1024.0, 1024, 0, 0, 1024, 1024]] * B, device="cuda")
+        return dict(x=r(B, 4, 32, 32), t=torch.randint(0, 1000, (B,), device="cuda", generator=g), eps=r(B, 4, 32, 32),
+                    kw={"encoder_hidden_states": r(B, 77, 2048), "added_cond_kwargs": {"text_embeds": r(B, 1280), "time_ids": ids}})
+
+    _full_depth_properties(model, inputs, 2, steps=3, lr=1e-5, add_tol=3e-2)

@@ -175,3 +175,36 @@ def test_dit_small_batch_forked_backward_equals_single_stream(monkeypatch):
         l2, mx = rel(g, ref)
         assert l2 < 1e-4 and mx < 1e-3, (l2, mx)
     assert model._side is not None
+
+
+@pytest.mark.parametrize("preset,dtype,B", [("DiT-S/2", "bf16", 64), ("DiT-S/2", "bf16", 16), ("DiT-S/2-RoPE", "bf16", 8),
+                                            ("DiT-S/2", "fp32", 2)], ids=["bf16_b64", "bf16_b16_forkable", "rope", "fp32"])
+def test_dit_block_recomputation_equals_plain_backward(preset, dtype, B):
+    """enable_gradient_checkpointing() (reference test_scripts/test_train.py:38-39): the forward keeps one block slab instead
+    of `depth`, the backward reruns each block from its kept input.  Same kernels on the same inputs, so the output is
+    bit-identical and every gradient equals the plain path's up to the order of its fp32 atomic adds; the workspace shrinks."""
+    from uwudiff_amd.dit import DiT
+
+    torch.manual_seed(21)
+    model = DiT.from_config(preset, cond_dim=1280, init="random", compute_dtype=dtype).cuda()
+    x, t = torch.randn(B, 4, 32, 32, device="cuda"), torch.randint(0, 1000, (B,), device="cuda").float()
+    c, w = torch.randn(B, 1280, device="cuda"), torch.randn(B, 4, 32, 32, device="cuda") / 4096
+
+    def run():
+        model.flat.grad = torch.zeros_like(model.flat.data)
+        out = model(x, t, added_cond_kwargs={"text_embeds": c})[0]
+        (out * w).sum().backward()
+        torch.cuda.synchronize()
+        return out.detach().clone(), model.flat.grad.clone(), model._ws.numel()
+
+    y0, g0, ws0 = run()
+    model.enable_gradient_checkpointing()
+    for _ in range(2):  # twice: the shared slab is reused across steps
+        y1, g1, ws1 = run()
+        assert torch.equal(y0, y1)
+        l2, mx = rel(g1, g0)
+        assert l2 < 1e-4 and mx < 1e-3, (l2, mx)
+    assert ws1 < (0.4 if B >= 16 else 0.6) * ws0, (ws0, ws1)  # (tiny batches: the fixed-size scratch regions weigh more)
+    model.enable_gradient_checkpointing(False)
+    y2, g2, ws2 = run()
+    assert torch.equal(y0, y2) and ws2 == ws0

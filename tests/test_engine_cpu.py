@@ -146,7 +146,7 @@ def test_foreign_optimizer_data_parallel_world2_gloo():
 def test_model_checkpoint_callback_writes_and_prunes(tmp_path):
     from uwudiff_amd.engine import Fitter, ModelCheckpoint
 
-    cb = ModelCheckpoint(dirpath=str(tmp_path), every_n_train_steps=2, save_top_k=2, save_last=True)
+    cb = ModelCheckpoint(dirpath=str(tmp_path), filename="step={step}", every_n_train_steps=2, save_top_k=2, save_last=True)
     tr = _FakeTrainer(torch.optim.SGD)
     fit = Fitter(max_steps=7, accelerator="cpu", callbacks=[cb], max_epochs=100)
     fit.fit(tr, _DM(scale=1.0))
@@ -158,6 +158,32 @@ def test_model_checkpoint_callback_writes_and_prunes(tmp_path):
     cb2 = ModelCheckpoint(dirpath=str(tmp_path / "dev"), every_n_train_steps=1)
     Fitter(fast_dev_run=True, accelerator="cpu", callbacks=[cb2]).fit(_FakeTrainer(torch.optim.SGD), _DM(1.0))
     assert not os.path.exists(tmp_path / "dev")
+
+
+def test_checkpoint_resume_continues_epoch_count_and_topk(tmp_path):
+    """the checkpoint stores the epoch it was written in; a resumed run continues from it (max_epochs bounds the
+    TOTAL, {epoch} in file names does not restart), top-k pruning remembers the files of the interrupted run, the default
+    file name is Lightning's, and save_top_k = 0 / -1 mean none / all."""
+    from uwudiff_amd.engine import Fitter, ModelCheckpoint
+
+    d = tmp_path / "a"
+    cb = ModelCheckpoint(dirpath=str(d), every_n_train_steps=1, save_top_k=2)
+    fit = Fitter(accelerator="cpu", callbacks=[cb], max_epochs=3)  # the fake loader has one batch per epoch
+    fit.fit(_FakeTrainer(torch.optim.SGD), _DM(1.0))
+    assert sorted(os.listdir(d)) == ["epoch=1-step=2.ckpt", "epoch=2-step=3.ckpt"]
+    ck = torch.load(d / "epoch=2-step=3.ckpt", weights_only=True)
+    assert ck["epoch"] == 2 and ck["global_step"] == 3
+    # resume from step 3 / epoch 2 with max_epochs = 5: exactly ... more epochs, numbered on
+    cb2 = ModelCheckpoint(dirpath=str(d), every_n_train_steps=1, save_top_k=2)
+    fit2 = Fitter(accelerator="cpu", callbacks=[cb2], max_epochs=5)
+    fit2.fit(_FakeTrainer(torch.optim.SGD), _DM(1.0), ckpt_path=str(d / "epoch=2-step=3.ckpt"))
+    assert fit2.global_step == 5 and fit2.current_epoch == 5  # epoch 2 was complete: two more epochs, numbered 3 and 4
+    assert sorted(os.listdir(d)) == ["epoch=3-step=4.ckpt", "epoch=4-step=5.ckpt"]  # the two files of run 1 were pruned
+    for k, want in ((0, []), (-1, ["epoch=0-step=1.ckpt", "epoch=1-step=2.ckpt", "epoch=2-step=3.ckpt"])):
+        dk = tmp_path / f"k{k}"
+        Fitter(accelerator="cpu", callbacks=[ModelCheckpoint(dirpath=str(dk), every_n_train_steps=1, save_top_k=k)],
+               max_epochs=3).fit(_FakeTrainer(torch.optim.SGD), _DM(1.0))
+        assert (sorted(os.listdir(dk)) if os.path.exists(dk) else []) == want
 
 
 def test_launcher_passes_resume_checkpoint_through():

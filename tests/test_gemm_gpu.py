@@ -460,3 +460,43 @@ def test_gemm_as_dgelu_matches_k_major_kernel(M, N):
     for _ in range(3):
         ops.gemm(dy, w2t, aux=u, epilogue=L.EPI_DGELU, out=got)
     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("N", [1024, 1088, 2048])
+def test_gemm_as_exact_integers_all_epilogues(N):
+    """The A-stationary kernel driven DIRECTLY on exact data: operands in {-1, 0, 1}, so every sum is a small
+    integer that bf16 holds exactly -- any fragment / chunk / interleaved-epilogue indexing error shows as a wrong integer.
+    All three epilogues of the kernel: bias (qkv forward), bias + GELU (fc1: pre-activation exact, activation within one bf16
+    step of tanh-GELU), and dGELU on aux values where gelu' is 0.5 / 1 / 0 (fc2 input gradient).  Reference: fp32 matmul
+    (exact on these integers).  M = 65536 rows of K = 384: the shapes for which the host rule picks gemm_as_kernel."""
+    import torch.nn.functional as F
+
+    from uwudiff_amd import lib as L
+    from uwudiff_amd import ops
+
+    M, K = 65536, 384
+    g = torch.Generator().manual_seed(77 + N)
+    a = torch.randint(-1, 2, (M, K), generator=g).float().cuda()
+    b = torch.randint(-1, 2, (N, K), generator=g).float().cuda()
+    bias = torch.randint(-8, 9, (N,), generator=g).float().cuda()
+    a16, b16 = a.bfloat16(), b.bfloat16()
+    ref = a @ b.t()
+    assert float(ref.abs().max()) + 8 < 256
+    # bias
+    y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(a16, b16, bias=bias, epilogue=L.EPI_BIAS, out=y)
+    assert torch.equal(y.float(), ref + bias)
+    # bias + GELU: two outputs
+    u, h = torch.empty_like(y), torch.empty_like(y)
+    ops.gemm(a16, b16, bias=bias, epilogue=L.EPI_BIAS_GELU, out=u, out2=h)
+    assert torch.equal(u.float(), ref + bias)
+    want = F.gelu(ref + bias, approximate="tanh")
+    assert float((h.float() - want).abs().max()) <= 2.0 ** -7 * float(want.abs().max())
+    exact = (ref + bias).abs() >= 8  # |x| >= 8: gelu(x) is x or 0 to fp32 precision
+    assert torch.equal(h.float()[exact], want.bfloat16().float()[exact])
+    # dGELU: aux in {0, 10, -10} -> gelu' in {0.5, 1, 0}
+    aux = (torch.randint(-1, 2, (M, N), generator=g).float() * 10).bfloat16().cuda()
+    d = torch.empty_like(y)
+    ops.gemm(a16, b16, aux=aux, epilogue=L.EPI_DGELU, out=d)
+    fac = torch.where(aux == 0, 0.5, torch.where(aux > 0, 1.0, 0.0)).float()
+    torch.testing.assert_close(d.float(), ref * fac, rtol=0, atol=1e-20)

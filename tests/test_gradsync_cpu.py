@@ -45,6 +45,20 @@ def _worker(rank, world, port, q):
     ok = ok and torch.allclose(g2, ref, rtol=0, atol=1e-6)
     ok = ok and cover[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(cover, cover[1:])) and sum(c[1] for c in cover) == n
     ok = ok and chunks2[:2] == [(40_000, 30_000), (70_000, 20_003)] and sync2._early == []
+    # single=True: north_star's exchange as stated -- one call over the whole buffer, no early slices
+    g3 = mine.clone()
+    sync3 = FlatGradSync(world, chunk_elems=30_000, single=True)
+
+    class _M:  # a model that would report early slices: single mode must not attach to it
+        hook = "unset"
+
+        def set_grad_ready_hook(self, h):
+            self.hook = h
+
+    m = _M()
+    sync3.attach(m)
+    chunks3 = sync3.all_reduce(g3)
+    ok = ok and m.hook == "unset" and chunks3 == [(0, n)] and torch.allclose(g3, ref, rtol=0, atol=1e-6)
     lo, hi = shard_range(50, rank, world)
     t = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -165,3 +165,25 @@ def test_concat_text_encoders_host_assembly_matches_reference_golden(name):
     assert (mask is None) == (not meta["has_mask"])
     if mask is not None:
         assert torch.equal(mask, d["mask"])
+
+
+def test_plain_clip_text_model_gets_layer_norm_of_the_chosen_layer():
+    """the reference recomputes normed_embedding = final_layer_norm(hidden_states[layer_idx]) for every
+    `isinstance(text_model, CLIPTextModel)` (text_encoders.py:190-192), i.e. by the class the YAML names -- both shipped YAMLs
+    name transformers.CLIPTextModel for both encoders.  CLIPTextModelWithProjection keeps LN(last layer)."""
+    from uwudiff_amd.conditioning import ConcatTextEncoders, SyntheticTokenizer
+    from uwudiff_amd.config import get_obj_from_str
+
+    tok = SyntheticTokenizer()(["a red fox", "two"])
+    cfg = dict(concat_bucket=0, use_pooled=True, layer_idx=-2)
+    for target, sd1 in (("transformers.CLIPTextModel.from_pretrained", True),
+                        ("transformers.CLIPTextModelWithProjection.from_pretrained", False)):
+        model = get_obj_from_str(target)(pretrained_model_name_or_path="x", subfolder="text_encoder")
+        assert (model.kind == "clip_sd1") == sd1
+        te = ConcatTextEncoders(tokenizers=["a"], text_model_and_configs=[(model, cfg)], zero_for_padding=False)
+        emb, normed, pooled, mask = te([tok])
+        last, _, hidden = model(tok["input_ids"], attention_mask=tok["attention_mask"], output_hidden_states=True)
+        torch.testing.assert_close(emb, hidden[-2])
+        want = model.final_layer_norm(hidden[-2]) if sd1 else last
+        torch.testing.assert_close(normed, want)
+        assert not torch.allclose(model.final_layer_norm(hidden[-2]), last)

@@ -77,6 +77,16 @@ class SyntheticTextModel(nn.Module):
         return (last, pooled, tuple(hidden)) if output_hidden_states else (last, pooled)
 
 
+class SyntheticCLIPTextModel(SyntheticTextModel):
+    """What ``transformers.CLIPTextModel`` resolves to (uwudiff_amd/config.py ALIASES): the reference recomputes
+    ``normed_embedding = final_layer_norm(hidden_states[layer_idx])`` for every plain ``CLIPTextModel`` -- an ``isinstance``
+    test (text_encoders.py:190-192) that ``CLIPTextModelWithProjection`` does not pass -- so the class a YAML names decides
+    it.  Both shipped YAMLs name ``CLIPTextModel`` for both SDXL encoders."""
+
+    def __init__(self, hidden=768, seed=0, kind="clip_sd1", **kw):
+        super().__init__(hidden=hidden, seed=seed, kind=kind, **kw)
+
+
 class _LatentDist:
     def __init__(self, mean, logvar):
         self.mean, self.logvar = mean, logvar

@@ -15,7 +15,7 @@ import yaml
 
 ALIASES = {
     "diffusers.EulerDiscreteScheduler": "uwudiff_amd.scheduler.EulerDiscreteScheduler",
-    "transformers.CLIPTextModel": "uwudiff_amd.conditioning.SyntheticTextModel",
+    "transformers.CLIPTextModel": "uwudiff_amd.conditioning.SyntheticCLIPTextModel",  # kind "clip_sd1": normed ctx = LN(layer_idx)
     "transformers.CLIPTextModelWithProjection": "uwudiff_amd.conditioning.SyntheticTextModel",
     "lightning.pytorch.callbacks.ModelCheckpoint": "uwudiff_amd.engine.ModelCheckpoint",
     "lightning.pytorch.callbacks.LearningRateMonitor": "uwudiff_amd.engine.LearningRateMonitor",

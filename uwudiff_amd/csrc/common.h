@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/uwu_hip.h"
 
@@ -36,6 +37,30 @@ void uwu_set_error(const char* fmt, ...);
     }                                                                           \
   } while (0)
 
+// ---- environment switches (A/B comparisons, sweeps, tests) --------------------------------------------------
+// Read once per switch and cached: a launch does not call getenv().  uwu_env_refresh() (api.cpp) bumps the generation so
+// that the next use re-reads -- the tests flip switches inside one process.
+int uwu_env_generation();
+struct UwuEnv {
+  const char* name;
+  int gen = -1, ival = 0;
+  bool set = false;
+  char c0 = 0;
+  explicit UwuEnv(const char* n) : name(n) {}
+  const UwuEnv& get() {
+    const int g = uwu_env_generation();
+    if (gen != g) {
+      const char* e = getenv(name);
+      set = e != nullptr;
+      c0 = e ? e[0] : 0;
+      ival = e ? atoi(e) : 0;
+      gen = g;
+    }
+    return *this;
+  }
+  bool is(char c) const { return set && c0 == c; }
+};
+
 // ---- live profiler hooks (prof.cpp) ------------------------------------------------------
 int uwu_prof_begin(void* stream);
 void uwu_prof_end(int slot, int tag, int kind, double flops, double bytes, void* stream);
@@ -59,15 +84,30 @@ template <>
 __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }  // RNE, NaN-safe (v_cvt_pk_bf16_f32)
 
 // ---- wave / block reductions ------------------------------------------------------------
+// Whole-wave reductions as six DPP steps + one v_readlane (result uniform in every lane).  __shfl_xor compiles to
+// ds_bpermute_b32 -- a trip through the LDS crossbar and an lgkmcnt wait per step; the LayerNorm kernels ran two such
+// dependent six-step chains per token row.  Steps: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror
+// (every lane of a 16-lane row then holds the row's value), row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2
+// and 3 (gfx9 DPP controls): lane 63 holds the wave's value.
+#define UWU_DPP_F(v, ctrl, rmask, ident) \
+  __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(ident)), __builtin_bit_cast(int, v), ctrl, rmask, 0xF, false))
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += UWU_DPP_F(v, 0xB1, 0xF, 0.f);
+  v += UWU_DPP_F(v, 0x4E, 0xF, 0.f);
+  v += UWU_DPP_F(v, 0x141, 0xF, 0.f);
+  v += UWU_DPP_F(v, 0x140, 0xF, 0.f);
+  v += UWU_DPP_F(v, 0x142, 0xA, 0.f);
+  v += UWU_DPP_F(v, 0x143, 0xC, 0.f);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, UWU_DPP_F(v, 0xB1, 0xF, v));
+  v = fmaxf(v, UWU_DPP_F(v, 0x4E, 0xF, v));
+  v = fmaxf(v, UWU_DPP_F(v, 0x141, 0xF, v));
+  v = fmaxf(v, UWU_DPP_F(v, 0x140, 0xF, v));
+  v = fmaxf(v, UWU_DPP_F(v, 0x142, 0xA, v));
+  v = fmaxf(v, UWU_DPP_F(v, 0x143, 0xC, v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 // Sum over each aligned group of 16 lanes (a DPP row), result in all 16: four v_add_f32 with DPP operands
 // (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror) -- no trip through the LDS crossbar that

@@ -28,6 +28,10 @@ struct Layout {
   // token path
   size_t tok, xe;
   size_t layer0, layer_stride;
+  // block recomputation (uwu_dit_desc.checkpoint): only the first `keep` bytes of a block's slab (x0 and the row statistics of
+  // its first LayerNorm) are per layer; every other sub-buffer lives ONCE at scratch0 + sub and holds the block in flight
+  bool ckpt;
+  size_t keep, scratch0;
   // per-layer sub-offsets
   size_t o_x0, o_m1, o_r1, o_h1, o_qkv, o_lse, o_ao, o_y1, o_x1, o_m2, o_r2, o_h2, o_u, o_f, o_y2;
   size_t o_rope;                     // rope mode: this layer's factor table [T, D] fp32
@@ -91,9 +95,12 @@ Layout make_layout(const uwu_dit_desc& d) {
     L.o_h2t = sub(L.M * L.D);
     L.o_ft = sub(L.M * L.D4);
   }
-  L.layer_stride = q;
+  L.keep = L.o_h1;  // o_x0, o_m1, o_r1 come first
+  L.ckpt = d.checkpoint != 0;
+  L.layer_stride = L.ckpt ? L.keep : q;
   L.layer0 = p;
   p += (size_t)d.L * L.layer_stride;
+  if (L.ckpt) L.scratch0 = take(q);
   L.xF = take(L.M * L.D * L.es);
   L.mF = take(L.M * f4);
   L.rF = take(L.M * f4);
@@ -368,7 +375,10 @@ struct Ptrs {
   template <typename T = void>
   T* at(size_t off) const { return reinterpret_cast<T*>(ws + off); }
   template <typename T = void>
-  T* lay(int l, size_t sub) const { return reinterpret_cast<T*>(ws + L.layer0 + (size_t)l * L.layer_stride + sub); }
+  T* lay(int l, size_t sub) const {
+    if (L.ckpt && sub >= L.keep) return reinterpret_cast<T*>(ws + L.scratch0 + sub);
+    return reinterpret_cast<T*>(ws + L.layer0 + (size_t)l * L.layer_stride + sub);
+  }
 };
 
 struct LayerW {
@@ -402,6 +412,59 @@ LayerW layer_weights(const uwu_dit_desc& d, int l) {
   w.fc1_b = d.w32 + w.off_fc1_b;
   w.fc2_b = d.w32 + w.off_fc2_b;
   return w;
+}
+
+
+// One transformer block of the forward pass.  recompute = true (block recomputation inside the backward): the block's
+// input x0 is the copy the forward kept, so its first LayerNorm takes it as is instead of forming it from the previous
+// block's pending MLP branch.
+int block_forward(const uwu_dit_desc& d, const Layout& L, const Ptrs& P, const F8& f8, int l, bool recompute, void* st) {
+  const int dt = d.dtype, B = d.B, T = d.T, D = d.D, M = (int)L.M, D3 = (int)L.D3, D4 = (int)L.D4;
+  const size_t es = L.es;
+  const float* w32 = d.w32;
+  const int ML = d.mod_total;
+  const float* mod = P.at<float>(L.mod);
+  const float scale = 1.f / sqrtf((float)(D / d.H));
+  const LayerW w = layer_weights(d, l);
+  const float* m = mod + (int64_t)l * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+  void* x0 = P.lay(l, L.o_x0);
+  // LN1 (+ pending MLP branch of the previous layer: x0 = x1_prev + gate_mlp_prev * y2_prev)
+  if (l == 0 || recompute) {  // (recompute: x0 of this block was kept; its statistics come out the same)
+    RUN(uwu_add_ln_modulate_fwd(x0, nullptr, nullptr, m + 0, m + D, ML, x0, P.lay(l, L.o_h1),
+                                P.lay<float>(l, L.o_m1), P.lay<float>(l, L.o_r1), B, T, D, d.ln_eps, 0, dt, st));
+  } else {
+    const float* mp = mod + (int64_t)(l - 1) * 6 * D;
+    RUN(uwu_add_ln_modulate_fwd(P.lay(l - 1, L.o_x1), P.lay(l - 1, L.o_y2), mp + 5 * D, m + 0, m + D, ML, x0,
+                                P.lay(l, L.o_h1), P.lay<float>(l, L.o_m1), P.lay<float>(l, L.o_r1), B, T, D,
+                                d.ln_eps, 0, dt, st));
+  }
+  if (d.fp8) RUN(f8_fwd(f8, P.lay(l, L.o_h1), P.lay(l, L.o_h1t), f8.w(l, 0, false), w.qkv_b, P.lay(l, L.o_qkv), nullptr, M, D3, D, f8.role(l, 0), f8.role(l, 8), UWU_EPI_BIAS));
+  else RUN(lin_fwd(P.lay(l, L.o_h1), w.qkv_w, w.qkv_b, P.lay(l, L.o_qkv), nullptr, M, D3, D, dt, dt, UWU_EPI_BIAS, st));
+  char* qkv = P.lay<char>(l, L.o_qkv);
+  if (d.rope) {  // this layer's factor table, then attention with q / k rotated while they are staged
+    const int64_t fo = (int64_t)l * d.H * (D / d.H / 4);
+    RUN(uwu_axial_rope_table(d.pos_xy, w32 + d.off_rope_h + fo, w32 + d.off_rope_w + fo, P.lay<float>(l, L.o_rope), T, d.H,
+                             D / d.H, D, st));
+    RUN(uwu_attention_rope_fwd(qkv, qkv + (size_t)D * es, qkv + (size_t)2 * D * es, P.lay<float>(l, L.o_rope), P.lay(l, L.o_ao),
+                               P.lay<float>(l, L.o_lse), B, T, d.H, D / d.H, D3, D3, D3, D, D, scale, dt, st));
+  } else
+  RUN(uwu_attention_fwd(qkv, qkv + (size_t)D * es, qkv + (size_t)2 * D * es, P.lay(l, L.o_ao), P.lay<float>(l, L.o_lse),
+                        B, T, T, d.H, D / d.H, D3, D3, D3, D, scale, dt, st));
+  if (d.fp8) RUN(f8_fwd(f8, P.lay(l, L.o_ao), P.lay(l, L.o_aot), f8.w(l, 1, false), w.o_b, P.lay(l, L.o_y1), nullptr, M, D, D, f8.role(l, 1), f8.role(l, 9), UWU_EPI_BIAS));
+  else RUN(lin_fwd(P.lay(l, L.o_ao), w.o_w, w.o_b, P.lay(l, L.o_y1), nullptr, M, D, D, dt, dt, UWU_EPI_BIAS, st));
+  // x1 = x0 + gate_msa * y1 ; h2 = LN(x1)*(1+scale_mlp)+shift_mlp
+  RUN(uwu_add_ln_modulate_fwd(x0, P.lay(l, L.o_y1), m + 2 * D, m + 3 * D, m + 4 * D, ML, P.lay(l, L.o_x1),
+                              P.lay(l, L.o_h2), P.lay<float>(l, L.o_m2), P.lay<float>(l, L.o_r2), B, T, D, d.ln_eps,
+                              0, dt, st));
+  if (d.fp8) {
+    RUN(f8_fwd(f8, P.lay(l, L.o_h2), P.lay(l, L.o_h2t), f8.w(l, 2, false), w.fc1_b, P.lay(l, L.o_u), P.lay(l, L.o_f), M, D4, D, f8.role(l, 2), f8.role(l, 10), UWU_EPI_BIAS_GELU));
+    RUN(f8_fwd(f8, P.lay(l, L.o_f), P.lay(l, L.o_ft), f8.w(l, 3, false), w.fc2_b, P.lay(l, L.o_y2), nullptr, M, D, D4, f8.role(l, 3), f8.role(l, 11), UWU_EPI_BIAS));
+  } else {
+    RUN(lin_fwd(P.lay(l, L.o_h2), w.fc1_w, w.fc1_b, P.lay(l, L.o_u), P.lay(l, L.o_f), M, D4, D, dt, dt,
+                UWU_EPI_BIAS_GELU, st));
+    RUN(lin_fwd(P.lay(l, L.o_f), w.fc2_w, w.fc2_b, P.lay(l, L.o_y2), nullptr, M, D, D4, dt, dt, UWU_EPI_BIAS, st));
+  }
+  return UWU_OK;
 }
 
 }  // namespace
@@ -469,48 +532,7 @@ extern "C" int uwu_dit_forward(const uwu_dit_desc* dp, const float* noisy, const
               dt, UWU_EPI_BIAS, st));
   RUN(uwu_add_pos(P.lay(0, L.o_x0), d.pos, B, T, D, dt, st));
 
-  const float scale = 1.f / sqrtf((float)(D / d.H));
-  for (int l = 0; l < d.L; ++l) {
-    const LayerW w = layer_weights(d, l);
-    const float* m = mod + (int64_t)l * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
-    void* x0 = P.lay(l, L.o_x0);
-    // LN1 (+ pending MLP branch of the previous layer: x0 = x1_prev + gate_mlp_prev * y2_prev)
-    if (l == 0) {
-      RUN(uwu_add_ln_modulate_fwd(x0, nullptr, nullptr, m + 0, m + D, ML, x0, P.lay(l, L.o_h1),
-                                  P.lay<float>(l, L.o_m1), P.lay<float>(l, L.o_r1), B, T, D, d.ln_eps, 0, dt, st));
-    } else {
-      const float* mp = mod + (int64_t)(l - 1) * 6 * D;
-      RUN(uwu_add_ln_modulate_fwd(P.lay(l - 1, L.o_x1), P.lay(l - 1, L.o_y2), mp + 5 * D, m + 0, m + D, ML, x0,
-                                  P.lay(l, L.o_h1), P.lay<float>(l, L.o_m1), P.lay<float>(l, L.o_r1), B, T, D,
-                                  d.ln_eps, 0, dt, st));
-    }
-    if (d.fp8) RUN(f8_fwd(f8, P.lay(l, L.o_h1), P.lay(l, L.o_h1t), f8.w(l, 0, false), w.qkv_b, P.lay(l, L.o_qkv), nullptr, M, D3, D, f8.role(l, 0), f8.role(l, 8), UWU_EPI_BIAS));
-    else RUN(lin_fwd(P.lay(l, L.o_h1), w.qkv_w, w.qkv_b, P.lay(l, L.o_qkv), nullptr, M, D3, D, dt, dt, UWU_EPI_BIAS, st));
-    char* qkv = P.lay<char>(l, L.o_qkv);
-    if (d.rope) {  // this layer's factor table, then attention with q / k rotated while they are staged
-      const int64_t fo = (int64_t)l * d.H * (D / d.H / 4);
-      RUN(uwu_axial_rope_table(d.pos_xy, w32 + d.off_rope_h + fo, w32 + d.off_rope_w + fo, P.lay<float>(l, L.o_rope), T, d.H,
-                               D / d.H, D, st));
-      RUN(uwu_attention_rope_fwd(qkv, qkv + (size_t)D * es, qkv + (size_t)2 * D * es, P.lay<float>(l, L.o_rope), P.lay(l, L.o_ao),
-                                 P.lay<float>(l, L.o_lse), B, T, d.H, D / d.H, D3, D3, D3, D, D, scale, dt, st));
-    } else
-    RUN(uwu_attention_fwd(qkv, qkv + (size_t)D * es, qkv + (size_t)2 * D * es, P.lay(l, L.o_ao), P.lay<float>(l, L.o_lse),
-                          B, T, T, d.H, D / d.H, D3, D3, D3, D, scale, dt, st));
-    if (d.fp8) RUN(f8_fwd(f8, P.lay(l, L.o_ao), P.lay(l, L.o_aot), f8.w(l, 1, false), w.o_b, P.lay(l, L.o_y1), nullptr, M, D, D, f8.role(l, 1), f8.role(l, 9), UWU_EPI_BIAS));
-    else RUN(lin_fwd(P.lay(l, L.o_ao), w.o_w, w.o_b, P.lay(l, L.o_y1), nullptr, M, D, D, dt, dt, UWU_EPI_BIAS, st));
-    // x1 = x0 + gate_msa * y1 ; h2 = LN(x1)*(1+scale_mlp)+shift_mlp
-    RUN(uwu_add_ln_modulate_fwd(x0, P.lay(l, L.o_y1), m + 2 * D, m + 3 * D, m + 4 * D, ML, P.lay(l, L.o_x1),
-                                P.lay(l, L.o_h2), P.lay<float>(l, L.o_m2), P.lay<float>(l, L.o_r2), B, T, D, d.ln_eps,
-                                0, dt, st));
-    if (d.fp8) {
-      RUN(f8_fwd(f8, P.lay(l, L.o_h2), P.lay(l, L.o_h2t), f8.w(l, 2, false), w.fc1_b, P.lay(l, L.o_u), P.lay(l, L.o_f), M, D4, D, f8.role(l, 2), f8.role(l, 10), UWU_EPI_BIAS_GELU));
-      RUN(f8_fwd(f8, P.lay(l, L.o_f), P.lay(l, L.o_ft), f8.w(l, 3, false), w.fc2_b, P.lay(l, L.o_y2), nullptr, M, D, D4, f8.role(l, 3), f8.role(l, 11), UWU_EPI_BIAS));
-    } else {
-      RUN(lin_fwd(P.lay(l, L.o_h2), w.fc1_w, w.fc1_b, P.lay(l, L.o_u), P.lay(l, L.o_f), M, D4, D, dt, dt,
-                  UWU_EPI_BIAS_GELU, st));
-      RUN(lin_fwd(P.lay(l, L.o_f), w.fc2_w, w.fc2_b, P.lay(l, L.o_y2), nullptr, M, D, D4, dt, dt, UWU_EPI_BIAS, st));
-    }
-  }
+  for (int l = 0; l < d.L; ++l) RUN(block_forward(d, L, P, f8, l, false, st));
   // ---- final adaLN + linear + unpatchify
   {
     const int l = d.L - 1;
@@ -548,7 +570,9 @@ extern "C" int uwu_dit_backward(const uwu_dit_desc* dp, const float* dout, void*
   const F8 f8{d.fp8, d.f8_scale, d.f8_amax, d.f8_fmt, P.at<char>(L.x8), nullptr, P.at<char>(L.dy8),
               P.at<char>(L.dy8t), P.at<char>(L.wsc), P.at<char>(L.w8), L.wsc_bytes, L.w8_layer, d.D, st};
   Fork fk{static_cast<hipStream_t>(st), {}, {}, false};
-  fk.on = d.side_stream && d.side_stream != st && !d.fp8 && dt == UWU_BF16 && M <= 16384 &&
+  // (block recomputation reuses ONE slab of saved activations: the recomputation of block l - 1 must not overtake a weight
+  // gradient of block l on another stream, so that mode keeps everything on the call's stream)
+  fk.on = d.side_stream && d.side_stream != st && !d.fp8 && dt == UWU_BF16 && M <= 16384 && !L.ckpt &&
           fork_resources(fk, static_cast<hipStream_t>(d.side_stream));
   char* const wsc = P.at<char>(L.wsc);  // region k of the split-K scratch belongs to the stream that fn(.., k) runs on
   bool side_used[4] = {false, false, false, false};  // a consumer-done event of this slot has been recorded in this call
@@ -661,6 +685,9 @@ extern "C" int uwu_dit_backward(const uwu_dit_desc* dp, const float* dout, void*
     }
     if (!d.fp8) RUN(lin_dgrad(dqkv, w.qkv_w, P.at(L.dh), nullptr, M, D3, D, dt, st));
     if (!d.fp8) RUN(join_side(fk, 2));  // LN1 backward rewrites dy: the proj weight gradient must have read it
+    // block recomputation: every saved tensor of block l except x0 / mean / rstd of its first LayerNorm is dead now -- rerun
+    // block l - 1 from its kept input into the shared slab (its y2 is needed right below, the rest by the next iteration)
+    if (L.ckpt && l > 0) RUN(block_forward(d, L, P, f8, l - 1, true, st));
     // LN1 bwd (+ residual) and gate bwd of the previous layer's MLP branch
     if (l > 0) {
       const float* mp = mod + (int64_t)(l - 1) * 6 * D;

@@ -1926,21 +1926,17 @@ int launch_big(GemmArgs g, hipStream_t st) {
 // A-stationary kernel: K = 384, whole 256-row panels, 64-column chunks, bf16 output with the paired 16-byte stores.
 // UWU_GEMM_AS=0 turns it off (A/B comparisons).
 static bool use_as(const GemmArgs& g, int out_bytes) {
-  const char* e = getenv("UWU_GEMM_AS");
-  if (e && e[0] == '0') return false;
-  static int nmin = -1;  // UWU_AS_NMIN=n: sweeps
-  if (nmin < 0) {
-    const char* t = getenv("UWU_AS_NMIN");
-    nmin = t ? atoi(t) : 1024;
-  }
+  static UwuEnv on("UWU_GEMM_AS"), nmin_e("UWU_AS_NMIN");  // UWU_AS_NMIN=n: sweeps
+  if (on.get().is('0')) return false;
+  const int nmin = nmin_e.get().set ? nmin_e.ival : 1024;
   // one workgroup per 256 rows: below one per CU the chip is under-filled (per-GPU batch 64: 9.8k -> 8.2k images/s with it)
   return g.K == AS_K && g.M % 256 == 0 && g.M >= 256 * 256 && g.N % AS_BN == 0 && g.N <= 2048 && g.N >= nmin && out_bytes == 2 &&
          g.lda % 8 == 0 &&
          g.ldb % 8 == 0 && g.ldc % 8 == 0 && (((uintptr_t)g.A | (uintptr_t)g.B | (uintptr_t)g.C | (uintptr_t)g.C2) & 15) == 0;
 }
 static bool use_as_bias() {  // the plain bias Linears with N >= 1024 (qkv forward: 285 -> 231 us in the step); UWU_GEMM_AS_BIAS=0: off
-  const char* e = getenv("UWU_GEMM_AS_BIAS");
-  return !(e && e[0] == '0');
+  static UwuEnv on("UWU_GEMM_AS_BIAS");
+  return !on.get().is('0');
 }
 template <typename TC, int EPI>
 int launch_as(GemmArgs g, hipStream_t st) {
@@ -1976,16 +1972,12 @@ int launch_m64(GemmArgs g, hipStream_t st) {
 }
 // 64x128 kernel: when the 128x128 grid has fewer tiles than the chip has CUs.  UWU_GEMM_M64=0 turns it off.
 static bool use_m64(const GemmArgs& g, bool tb) {
-  const char* e = getenv("UWU_GEMM_M64");
-  if (e && e[0] == '0') return false;
+  static UwuEnv on("UWU_GEMM_M64"), thr_e("UWU_M64_TILES");  // UWU_M64_TILES=n: sweeps
+  if (on.get().is('0')) return false;
   if (g.K % 64 || (((uintptr_t)g.A | (uintptr_t)g.B) & 15) || g.lda % 8 || g.ldb % 8) return false;
   if (tb && (g.N % 8 || g.N < 8)) return false;
   const int64_t tiles = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128);
-  static int thr = -1;  // UWU_M64_TILES=n: sweeps
-  if (thr < 0) {
-    const char* t = getenv("UWU_M64_TILES");
-    thr = t ? atoi(t) : 256;
-  }
+  const int thr = thr_e.get().set ? thr_e.ival : 256;
   return tiles < thr && g.M > 64;
 }
 template <typename TC, int EPI, bool TB>
@@ -2011,9 +2003,9 @@ int launch_wide(GemmArgs g, hipStream_t st) {
 // fill rule.  UWU_GEMM_WIDE=0 turns it off, =1 forces it (tests, A/B comparisons).
 static bool use_wide(const GemmArgs& g) {
   if (g.K % 64 || g.N % 384 || g.N % 256 == 0) return false;
-  const char* e = getenv("UWU_GEMM_WIDE");
-  if (e && e[0] == '0') return false;
-  if (e && e[0] == '1') return true;
+  static UwuEnv on("UWU_GEMM_WIDE");
+  if (on.get().is('0')) return false;
+  if (on.is('1')) return true;
   const int64_t tiles = (int64_t)((g.M + 191) / 192) * (g.N / 384);
   const int64_t rounds = (tiles + 255) / 256;
   return tiles * 100 >= rounds * 256 * 85;
@@ -2025,8 +2017,8 @@ static bool use_wide(const GemmArgs& g) {
 // (A masked ragged last column tile was tried on DiT-XL/2's N = 3456 / 1152 Linears: +0.4 % at 4 % padding, -1.8 % at
 // 11 % -- not taken.)
 static bool use_big(const GemmArgs& g) {
-  const char* e = getenv("UWU_GEMM_BIG");
-  return !(e && e[0] == '0') && g.K % 64 == 0 && g.N % 256 == 0;
+  static UwuEnv on("UWU_GEMM_BIG");
+  return !on.get().is('0') && g.K % 64 == 0 && g.N % 256 == 0;
 }
 // C[m][n] += sum over the split-K slices of the scratch [split][M][N]; one float4 per thread
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ C,
@@ -2046,11 +2038,8 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
 // Outputs with >= 64 tiles of a reduction of a few thousand rows: fewer slices, the XCDs divided between slices and tiles
 // (gemm_tr_kernel's xs): every halving of the slice count halves the fp32 slice traffic.
 int tr_split(int tiles, int steps) {
-  static int forced = -1;  // UWU_TR_SPLIT=n: sweeps
-  if (forced < 0) {
-    const char* e = getenv("UWU_TR_SPLIT");
-    forced = e ? atoi(e) : 0;
-  }
+  static UwuEnv forced_e("UWU_TR_SPLIT"), min_e("UWU_TR_MINSTEPS");  // sweeps
+  const int forced = forced_e.get().ival;
   int split;
   if (forced > 0) {
     split = forced;
@@ -2064,11 +2053,7 @@ int tr_split(int tiles, int steps) {
     int per_xcd = 64 / tiles;
     if (per_xcd < 1) per_xcd = 1;
     split = 8 * per_xcd;
-    static int min_steps = -1;  // UWU_TR_MINSTEPS=n: sweeps
-    if (min_steps < 0) {
-      const char* e = getenv("UWU_TR_MINSTEPS");
-      min_steps = e ? atoi(e) : 32;
-    }
+    const int min_steps = min_e.get().set ? min_e.ival : 32;
     while (split > 8 && split * min_steps > steps) split -= 8;  // keep >= 32 K-steps per slice (batch 16: 3.82k -> 4.13k img/s, batch 64: 9.05k -> 9.79k with the four side streams)
   }
   if (split > steps) split = steps;
@@ -2137,11 +2122,11 @@ int trw_split(int tiles, int steps) {
 }
 // 0 = not taken, 1 = 192 x 384 tiles, 2 = 384 x 192 tiles.  UWU_GEMM_TRW=0 turns it off (A/B comparisons).
 int pick_trw(const GemmArgs& g) {
-  const char* e = getenv("UWU_GEMM_TRW");
-  if (e && e[0] == '0') return 0;
+  static UwuEnv on("UWU_GEMM_TRW");
+  if (on.get().is('0')) return 0;
   // short reductions (per-GPU batch < 128 images): the 4-stage ring of a whole-LDS workgroup barely fills and nothing else fits
   // on its CU; the 256x128 kernel (two workgroups per CU) measured 1-2 % faster there.  UWU_GEMM_TRW=1 forces it (tests).
-  const bool force = e && e[0] == '1';
+  const bool force = on.is('1');
   if (g.K % 32 || g.K < (force ? 4096 : 32768) || g.M % 8 || g.N % 8) return 0;
   if ((((uintptr_t)g.A | (uintptr_t)g.B) & 15) || g.lda % 8 || g.ldb % 8) return 0;
   if (g.N % 384 == 0 && g.M >= 192) return 1;
@@ -2183,8 +2168,8 @@ int launch_trw(GemmArgs g, void* scratch, hipStream_t st) {
 }
 // K-major x K-major accumulate (the weight gradients): 0 = keep the 128x128 kernel, 1 = 256x128, 2 = 128x256
 int pick_tr(const GemmArgs& g) {
-  const char* e = getenv("UWU_GEMM_TR");  // "0": off (A/B comparisons)
-  if (e && e[0] == '0') return 0;
+  static UwuEnv on("UWU_GEMM_TR");  // "0": off (A/B comparisons)
+  if (on.get().is('0')) return 0;
   if (g.K % 32 || g.K < 96 || g.M % 8 || g.N % 8 || g.M < 8 || g.N < 8) return 0;
   if ((((uintptr_t)g.A | (uintptr_t)g.B) & 15) || g.lda % 8 || g.ldb % 8) return 0;
   auto padded = [](int x, int b) { return (double)(((x + b - 1) / b) * b) / x; };
@@ -2200,34 +2185,25 @@ int pick_tr(const GemmArgs& g) {
 // (N = 384) the second round of 512 workgroup slots would be half empty.  The 128x128 ring (4 stages) replaces
 // gemm_kernel's register-staged input-gradient path (K-major weight: qkv dgrad 96 -> 70 us, fc1 dgrad 111 -> 90).
 int pick_r3(const GemmArgs& g, bool tb) {
-  const char* e = getenv("UWU_GEMM_R3");  // "0": off (A/B comparisons)
-  if (e && e[0] == '0') return 0;
+  static UwuEnv on("UWU_GEMM_R3"), t8_e("UWU_R3_T8"), t4_e("UWU_R3_T4");  // "0": off (A/B comparisons); thresholds: sweeps
+  if (on.get().is('0')) return 0;
   if (g.K % 32 || g.K < 96) return 0;
   if ((((uintptr_t)g.A | (uintptr_t)g.B) & 15) || g.lda % 8 || g.ldb % 8) return 0;
   if (tb && (g.N % 8 || g.N < 8)) return 0;
-  static int thr8 = -1, thr4 = -1;  // tile-count thresholds (env overrides for sweeps)
-  if (thr8 < 0) {
-    const char* e8 = getenv("UWU_R3_T8");
-    const char* e4 = getenv("UWU_R3_T4");
-    thr8 = e8 ? atoi(e8) : 512;  // sweep at per-GPU batches 16..256: 512 / 128 never lose
-    thr4 = e4 ? atoi(e4) : 128;
-  }
+  const int thr8 = t8_e.get().set ? t8_e.ival : 512;  // sweep at per-GPU batches 16..256: 512 / 128 never lose
+  const int thr4 = t4_e.get().set ? t4_e.ival : 128;
   const int64_t t8 = (int64_t)((g.M + 255) / 256) * ((g.N + 127) / 128);
   // long contractions (the UNet's K = 640 .. 5120): the larger tile's operand reuse pays from one workgroup per CU on
   // (SDXL shape, 12 x 4x128x128: 480 tiles of 256x128 per 1280-wide Linear; 30.6 -> 31.8 images/s)
-  static const bool t8_env = getenv("UWU_R3_T8") != nullptr;
+  const bool t8_env = t8_e.set;
   if (t8 >= ((g.K >= 640 && !t8_env) ? 256 : thr8)) return 8;
   const int64_t t4 = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128);
   return (tb && t4 >= thr4) ? 4 : 0;  // K-contiguous B at N = 384: gemm_kernel's 128-byte rows measured faster (proj 35 vs 43 us)
 }
 
 bool no_glds() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("UWU_GEMM_NO_GLDS");
-    v = (e && e[0] == '1') ? 1 : 0;
-  }
-  return v == 1;
+  static UwuEnv on("UWU_GEMM_NO_GLDS");
+  return on.get().is('1');
 }
 
 template <typename T, typename TC>
@@ -2542,8 +2518,8 @@ extern "C" int uwu_gemm(const void* A, const void* B, void* C, void* C2, const f
             (C2 == nullptr || epilogue == UWU_EPI_DGELU || ((uintptr_t)C2 & 15) == 0)) ? 1 : 0;
   g.aux16 = (epilogue == UWU_EPI_DGELU && dtype == UWU_BF16 && N % 8 == 0 && ldaux % 8 == 0 && ((uintptr_t)aux & 15) == 0) ? 1 : 0;
   {
-    const char* e16 = getenv("UWU_GEMM_AUX16");  // "0": the 8-byte aux loads (A/B comparisons)
-    if (e16 && e16[0] == '0') g.aux16 = 0;
+    static UwuEnv a16("UWU_GEMM_AUX16");  // "0": the 8-byte aux loads (A/B comparisons)
+    if (a16.get().is('0')) g.aux16 = 0;
   }
 
   const int ktiles = (K + bk - 1) / bk;

@@ -34,7 +34,7 @@ class ModelCheckpoint:
     def __init__(self, dirpath=None, filename=None, every_n_train_steps=None, every_n_epochs=None, save_last=False,
                  save_top_k=None, **kw):
         self.dirpath = dirpath or "checkpoints"
-        self.filename = filename or "step={step}"
+        self.filename = filename or "epoch={epoch}-step={step}"  # Lightning's default name
         self.every_n_train_steps = int(every_n_train_steps) if every_n_train_steps else None
         self.every_n_epochs = int(every_n_epochs) if every_n_epochs else None
         self.save_last = bool(save_last)
@@ -43,9 +43,11 @@ class ModelCheckpoint:
         self.saved = []
 
     def _save(self, fitter, path):
-        fitter.save_checkpoint(path)
-        self.saved.append(path)
         k = self.save_top_k
+        if k == 0:  # Lightning: save_top_k = 0 keeps no periodic file (save_last still writes "last"), -1 keeps all
+            return
+        fitter.save_checkpoint(path, callbacks={"ModelCheckpoint": {"saved": self.saved + [path]}})
+        self.saved.append(path)
         if k is not None and k > 0 and fitter.global_rank == 0:
             while len(self.saved) > k:
                 old = self.saved.pop(0)
@@ -152,7 +154,7 @@ class Fitter:
     # Lightning's checkpoint layout (the keys `Trainer.fit(ckpt_path=...)` and the reference's loader read:
     # loader.py:24-46 extracts `state_dict` entries by prefix, e.g. "unet."): the module's state_dict carries the
     # denoiser as `unet.<diffusers-style names>`, optimizer / scheduler states are the torch ones.
-    def save_checkpoint(self, path):
+    def save_checkpoint(self, path, callbacks=None):
         """Write the state of the current / last ``fit`` (rank 0 only).  Returns the dict that was saved."""
         module, opt, sched = self._fit_state
 
@@ -165,7 +167,8 @@ class Fitter:
                 return type(o)(snap(v) for v in o)
             return o
 
-        ckpt = {"epoch": 0, "global_step": self.global_step, "pytorch-lightning_version": "uwudiff_amd",
+        ckpt = {"epoch": self.current_epoch, "global_step": self.global_step, "pytorch-lightning_version": "uwudiff_amd",
+                "callbacks": callbacks or {},
                 "state_dict": snap(dict(module.state_dict())),
                 "optimizer_states": [snap(opt.state_dict())],
                 "lr_schedulers": [sched.state_dict()] if sched is not None and hasattr(sched, "state_dict") else []}
@@ -192,6 +195,12 @@ class Fitter:
         if sched is not None and ckpt.get("lr_schedulers") and hasattr(sched, "load_state_dict"):
             sched.load_state_dict(ckpt["lr_schedulers"][0])
         self.global_step = int(ckpt["global_step"])
+        self.current_epoch = int(ckpt.get("epoch", 0))
+        saved = (ckpt.get("callbacks") or {}).get("ModelCheckpoint", {}).get("saved")
+        if saved is not None:  # top-k pruning continues over the files the interrupted run had written
+            for cb in self.callbacks:
+                if isinstance(cb, ModelCheckpoint):
+                    cb.saved = list(saved)
         return ckpt
 
     def _to_device(self, batch):
@@ -232,10 +241,13 @@ class Fitter:
         params = [p for g in opt.param_groups for p in g["params"]]
         max_steps = 1 if self.fast_dev_run else self.max_steps
         t0 = time.time()
-        epoch = 0
+        epoch = self.current_epoch if ckpt_path is not None else 0  # a resumed run continues its epoch count (max_epochs, {epoch})
         done = False
         # resume mid-epoch like Lightning does: skip the batches the interrupted epoch had already consumed
         resume_skip = (self.global_step % max(len(loader), 1)) if ckpt_path is not None else 0
+        if ckpt_path is not None and resume_skip == 0 and self.global_step > 0:
+            epoch += 1  # the checkpoint was written after the last batch of its epoch: that epoch is complete
+        self.current_epoch = epoch
         while not done:
             for bi, batch in enumerate(loader):
                 if bi < resume_skip:

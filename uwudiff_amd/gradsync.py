@@ -46,12 +46,22 @@ class _DirectRccl:
             L.call("uwu_comm_init", raw, rank, world, ctypes.byref(self.comm))
 
     def all_reduce(self, t, stream):
+        # uwu_allreduce_flat takes a count of ncclFloat32 elements: anything else would silently reduce the wrong bytes.
+        # UNVERIFIED at world > 1 (no multi-GPU box in the build loop; the world-1 identity test is all that ran): opt-in only.
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise TypeError(f"uwu_allreduce_flat reduces contiguous float32 slices (got {t.dtype}, contiguous={t.is_contiguous()})")
         self.L.call("uwu_allreduce_flat", self.comm, t.data_ptr(), t.numel(), stream.cuda_stream)
 
 
 class FlatGradSync:
-    def __init__(self, world_size=None, chunk_elems=8 * 1024 * 1024, group=None):
+    def __init__(self, world_size=None, chunk_elems=8 * 1024 * 1024, group=None, single=False):
+        """``single=True``: north_star's exchange as literally stated -- ONE all-reduce of the whole flat buffer after the
+        backward (no early block-group reductions, no chunks), AdamW behind its one event.  The default overlaps: block
+        groups are reduced from inside the backward and the rest in ``chunk_elems`` pieces.  Same object, same call sites,
+        so the 8-GPU run can A/B the two (``bench.py --single-allreduce``)."""
         self.group = group
+        self.single = bool(single)
+        self.path = None  # which exchange ran last: "torch.distributed" | "uwu_allreduce_flat (direct RCCL)" (bench `comm.backend`)
         self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.chunk_elems = int(chunk_elems)
         self._comm_stream = None
@@ -64,7 +74,7 @@ class FlatGradSync:
         return 1.0 / self.world
 
     def chunks(self, n):
-        c = self.chunk_elems
+        c = n if self.single else self.chunk_elems
         return [(o, min(c, n - o)) for o in range(0, n, c)]
 
     def _stream(self, device):
@@ -78,13 +88,15 @@ class FlatGradSync:
             if self._direct is None:
                 self._direct = _DirectRccl(t.device, self.group)
             self._direct.all_reduce(t, comm_stream)
+            self.path = "uwu_allreduce_flat (direct RCCL communicator)"
         else:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            self.path = f"torch.distributed/{dist.get_backend(self.group)}"
 
     def attach(self, model):
         """Reduce the slices ``model`` reports as final from inside its backward (no-op for one rank or for models
         without ``set_grad_ready_hook``).  Call once, after the model is on its device."""
-        if self.world > 1 and hasattr(model, "set_grad_ready_hook"):
+        if self.world > 1 and not self.single and hasattr(model, "set_grad_ready_hook"):
             model.set_grad_ready_hook(self._on_ready)
         return self
 
@@ -120,7 +132,7 @@ class FlatGradSync:
         rest, pos = [], 0
         for off, ln, _ in early + [(n, 0, None)]:
             while pos < off:
-                step = min(self.chunk_elems, off - pos)
+                step = off - pos if self.single else min(self.chunk_elems, off - pos)
                 rest.append((pos, step))
                 pos += step
             pos = max(pos, off + ln)

@@ -34,6 +34,7 @@ class DitDesc(ctypes.Structure):
         + [("side_stream", c_void_p)]
         + [("rope", c_int32), ("off_rope_h", c_int64), ("off_rope_w", c_int64), ("pos_xy", c_void_p)]
         + [("fp8", c_int32), ("f8_scale", c_void_p), ("f8_amax", c_void_p), ("f8_fmt", c_void_p)]
+        + [("checkpoint", c_int32)]
     )
 
 
@@ -41,6 +42,7 @@ P = c_void_p
 _SIGS = {
     "uwu_last_error": (c_char_p, []),
     "uwu_version": (c_int, []),
+    "uwu_env_refresh": (c_int, []),
     "uwu_schedule_gather": (c_int, [P, P, P, P, c_int, c_int, c_int, c_float, c_int, P, P]),
     "uwu_rf_time_to_sigma": (c_int, [P, c_float, P, c_int, c_int, P, P, P]),
     "uwu_qsample": (c_int, [P, P, P, c_int, c_int64, P, P, P]),

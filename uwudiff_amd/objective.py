@@ -245,13 +245,35 @@ class RectifiedFlowLoss(DiffusionLoss):
             noises = (noises / noises.std([1, 2, 3], keepdim=True)).contiguous()
         return x, noises
 
-    # rectified_flow.py:63-96
-    def forward(self, x: torch.Tensor, unet: nn.Module, **unet_kwargs):
-        pt = self._type_id(self.prediction_type, "prediction")
+    def _prenormalise(self, x):
+        """The reference normalises the VAE latent BEFORE the loss sees it (trainer.py:241-244), so ``rescale_image`` takes the
+        per-sample std of the normalised latent: with that flag (or a 5-D sample+noise input) the normalisation cannot ride
+        in the q-sample kernel and is applied here, first.  Returns (x, done)."""
+        if self._latent_norm is not None and (self.rescale_image or x.dim() == 5):
+            mean, std = self._latent_norm
+            if x.dim() == 5:  # [B, 2, C, H, W]: plane 0 is the latent, plane 1 the injected noise
+                x = x.float().clone()
+                x[:, 0] = (x[:, 0] - mean) / std
+                return x, True
+            return (x.float() - mean) / std, True
+        return x, False
+
+    def _forward_process(self, x):
+        """(clean latent, noises, timesteps, coef, noisy latent) in the reference's order of operations"""
+        x, normed = self._prenormalise(x)
         x, noises = self.get_x0_and_noises(x)
         timesteps, coef = self.sample_timesteps_and_sigmas(x)
         self._inject = None
-        x, noisy = self._qsample_normed(x, noises, coef)
+        if normed:
+            noisy = self._qsample(x, noises, coef)
+        else:
+            x, noisy = self._qsample_normed(x, noises, coef)
+        return x, noises, timesteps, coef, noisy
+
+    # rectified_flow.py:63-96
+    def forward(self, x: torch.Tensor, unet: nn.Module, **unet_kwargs):
+        pt = self._type_id(self.prediction_type, "prediction")
+        x, noises, timesteps, coef, noisy = self._forward_process(x)
         model_output = unet(noisy, timesteps, **unet_kwargs)[0]
         loss, losses, pred, target = _FusedLoss.apply(model_output, x, noises, noisy, coef, pt, L.PT["rectified_flow"],
                                                       True)
@@ -285,10 +307,7 @@ class NNWeightedRFLoss(RectifiedFlowLoss):
 
     def forward(self, x: torch.Tensor, unet: nn.Module, **unet_kwargs):
         pt = self._type_id(self.prediction_type, "prediction")
-        x, noises = self.get_x0_and_noises(x)
-        timesteps, coef = self.sample_timesteps_and_sigmas(x)
-        self._inject = None
-        noisy = self._qsample(x, noises, coef)
+        x, noises, timesteps, coef, noisy = self._forward_process(x)  # (incl. the VAE latent normalisation, as every loss)
         model_output = unet(noisy, timesteps, **unet_kwargs)[0]
         sigmas = coef[:, 0]
         log_ls_pred = self.loss_pred_module(noisy, sigmas, **unet_kwargs).flatten()  # takes sigmas (:180-183)

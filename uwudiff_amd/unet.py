@@ -6,15 +6,17 @@ SDXL shape.  This module keeps the call contract (diffusion.py:172-176), diffuse
 ``state_dict()`` and the init rule, and runs every operator through ``libuwu_hip.so``:
 
   * activations channels-last / token-major ``[B*H*W, C]`` (bf16 in bf16 mode): Linear, attention and LayerNorm
-    consume them as they are; a 3x3 convolution is ``uwu_im2col3x3`` + the MFMA GEMM (K = 9*C), its data gradient
-    the GEMM + ``uwu_col2im3x3`` (gather form), its weight gradient the split-K GEMM on the recomputed columns;
+    consume them as they are; a 3x3 convolution (C and Cout multiples of 32, bf16) is an IMPLICIT GEMM -- the ring
+    kernels gather their activation operand per (tap, 32-channel chunk) with LDS-DMA, forward, input gradient (flipped
+    taps) and weight gradient alike; no im2col matrix exists in HBM.  conv_in (4 channels) and the
+    fp32 parity mode keep ``uwu_im2col3x3`` + GEMM / ``uwu_col2im3x3``;
   * GroupNorm(+SiLU), affine LayerNorm, GEGLU, nearest upsample, time-embedding broadcast-add are dedicated
-    kernels; self-attention uses the MFMA flash kernels, cross-attention (77 context tokens) the generic one;
+    kernels; self- and cross-attention (77 context tokens, optional key bias) run on the MFMA flash kernels;
   * all parameters live in one flat fp32 buffer (+ bf16 shadow) and gradients accumulate into ``flat.grad`` from
     inside the kernels, so the optimizer and the data-parallel exchange are the same single launches as for DiT.
 
-The graph is composed in Python (one ``autograd.Function`` per fused op); unlike the DiT there is no C++ driver yet,
-so small batches are host-bound -- the next step for this model is a driver like csrc/dit.cpp.
+The graph is composed in Python (one ``autograd.Function`` per fused op, ~4000 launches per step); the host enqueues a
+step in about a fifth of the time the GPU needs for it (bench line ``host_enqueue_ms``), so this is not the limiter.
 """
 import collections
 import math
@@ -93,6 +95,9 @@ class _Ctx:
     def _join(self):
         self._join_queued = False
         torch.cuda.current_stream().wait_stream(self.side)
+        # everything the main stream launches from here on is ordered behind the side stream, so the operands the queued
+        # weight gradients read can go back to the allocator now (they were held across the next forward before: several GB)
+        self._held.clear()
 
     def add(self, name, shape):
         self.registry[name] = (self.n, tuple(shape))
