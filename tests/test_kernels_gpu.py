@@ -131,6 +131,67 @@ def test_attention_fwd_bwd(B, Tq, Tk, H, d, packed, dtype):
     cmp(dv, vr.grad.transpose(1, 2).reshape(B * Tk, D), **t)
 
 
+@pytest.mark.parametrize("B,H,packed", [(1, 1, True), (100, 6, True), (43, 7, False), (768, 6, True)],
+                         ids=["1head", "600heads", "301heads_unpacked", "bench_4608heads"])
+def test_attention_p256_kernels_are_bit_identical_to_the_per_head_kernels(B, H, packed, monkeypatch):
+    """T = 256, head dim 64: the persistent LDS-DMA backward (attention_p256.hip: heads streamed through a ring, transposing LDS
+    reads instead of transposed images, K / V fragments reloaded per head) issues the same MFMA sequence per output as the
+    one-workgroup-per-head kernel (UWU_ATTN_P256=0), which the SDPA comparisons above pin -- so dq / dk / dv must agree BIT FOR
+    BIT, for 1 head, for head counts that give workgroups unequal shares (600 = 2.3 per CU, 301) and for the bench's 4608.
+    Three launches each: the ring / prefetch pipeline must not depend on timing.  Plus an fp64 check of the first heads."""
+    from uwudiff_amd import ops
+
+    T, d = 256, 64
+    D = H * d
+    g = torch.Generator(device="cuda").manual_seed(100 + B)
+    if packed:
+        qkv = torch.randn(B * T, 3 * D, device="cuda", generator=g).bfloat16()
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    else:
+        q, k, v = (torch.randn(B * T, D, device="cuda", generator=g).bfloat16() for _ in range(3))
+    do = (torch.randn(B * T, D, device="cuda", generator=g) * 0.5).bfloat16()
+    # forward: the persistent kernel (K / V tiles through a six-slot LDS-DMA ring, V^T by transposing reads) against the
+    # two-workgroups-per-head kernel (UWU_ATTN_P256F=0): same arithmetic per element -> o and lse bit for bit
+    fo = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("UWU_ATTN_P256F", flag)
+        for rep in range(3 if flag == "1" else 1):
+            o, lse = ops.attention_fwd(q, k, v, B, T, T, H, d)
+            if flag in fo:
+                assert torch.equal(o, fo[flag][0]) and torch.equal(lse, fo[flag][1]), "launch-to-launch difference (forward)"
+            fo[flag] = (o.clone(), lse.clone())
+    assert torch.isfinite(fo["1"][0].float()).all() and torch.isfinite(fo["1"][1]).all()
+    assert torch.equal(fo["1"][0], fo["0"][0]), float((fo["1"][0].float() - fo["0"][0].float()).abs().max())
+    assert torch.equal(fo["1"][1], fo["0"][1])
+    outs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("UWU_ATTN_P256", flag)
+        for rep in range(3 if flag == "1" else 1):
+            if packed:
+                dqkv = torch.full_like(qkv, float("nan"))
+                dq, dk, dv = dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:]
+            else:
+                dq, dk, dv = (torch.full_like(q, float("nan")) for _ in range(3))
+            ops.attention_bwd(q, k, v, o, do, lse, dq, dk, dv, B, T, T, H, d)
+            got = (dq.clone(), dk.clone(), dv.clone())
+            if flag in outs:
+                assert all(torch.equal(x, y) for x, y in zip(got, outs[flag])), "launch-to-launch difference"
+            outs[flag] = got
+    for name, x, y in zip(("dq", "dk", "dv"), outs["1"], outs["0"]):
+        assert torch.isfinite(x.float()).all(), name
+        assert torch.equal(x, y), (name, float((x.float() - y.float()).abs().max()))
+    # the first two samples against fp64 attention on the host
+    nb = min(B, 2)
+    def heads(t):
+        return t[:nb * T].double().cpu().reshape(nb, T, H, d).transpose(1, 2)
+    qr, kr, vr = [heads(t).requires_grad_(True) for t in (q, k, v)]
+    F.scaled_dot_product_attention(qr, kr, vr).backward(heads(do))
+    for x, ref in zip(outs["1"], (qr.grad, kr.grad, vr.grad)):
+        ref = ref.transpose(1, 2).reshape(nb * T, D)
+        err = (x[:nb * T].double().cpu() - ref).abs().max().item()
+        assert err < 2e-2 * ref.abs().max().item() + 1e-3, err
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,Tq,Tk,H,d", [(2, 64, 77, 2, 64), (2, 1024, 77, 3, 64), (1, 256, 256, 2, 64),
                                          (2, 128, 300, 1, 64), (2, 100, 40, 3, 72), (3, 64, 5, 1, 32),

@@ -1,0 +1,174 @@
+"""Host-side model of the LDS images of the T = 256 attention kernels (csrc/attention_p256.hip): fills the swizzled images
+the way the LDS-DMA does, performs the row reads and the transposing reads (ds_read_b64_tr_b16 semantics, cdna_hip_programming.md
+T10) with the kernel's per-lane address formulas, and checks (1) every MFMA operand fragment holds the matrix elements its lane
+map asks for and (2) no access pattern has an LDS bank conflict (bank model: MI355X_MICROARCH.md section LDS).
+No GPU needed: python tools/model_attn_lds.py"""
+import numpy as np
+
+# ---- swizzles (must match the kernel)
+def fsw(row):  # 16-byte chunk swizzle of 128-byte-row images: bit0 = r2^r4, bit1 = r3^r4, bit2 = r1
+    return (((row >> 2) ^ (row >> 4)) & 1) | ((((row >> 3) ^ (row >> 4)) & 1) << 1) | (((row >> 1) & 1) << 2)
+
+def off128(row, chunk):
+    return row * 128 + ((chunk ^ fsw(row)) << 4)
+
+def Fsw(row):  # 8-byte slot swizzle of the dS^T image: bit0 = r0, bit1 = r2, bit2 = r3, bit3 = r1
+    return (row & 1) | (((row >> 2) & 1) << 1) | (((row >> 3) & 1) << 2) | (((row >> 1) & 1) << 3)
+
+def offds(row, slot8):
+    return row * 128 + ((slot8 ^ Fsw(row)) << 3)
+
+# ---- bank model
+B128_GROUPS = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+B128_GROUPS += [[l + 32 for l in g] for g in B128_GROUPS]
+HALVES = [list(range(32)), list(range(32, 64))]
+W64 = [list(range(16 * i, 16 * i + 16)) for i in range(4)]
+
+def cyc(addrs, width, groups, nbanks):
+    tot = 0
+    for g in groups:
+        ba = {}
+        for l in g:
+            for w in range(0, width, 4):
+                ba.setdefault(((addrs[l] + w) // 4) % nbanks, set()).add((addrs[l] + w) // 4)
+        tot += max(len(v) for v in ba.values())
+    return tot
+
+def tr_read(mem, addrs):
+    """ds_read_b64_tr_b16: per 16-lane group, lane 4q+p supplies the address of row q, columns 4p..4p+3; lane i receives column i of
+    the 4 rows (element q = row q).  mem: uint16 array indexed by byte address / 2."""
+    out = np.zeros((64, 4), dtype=mem.dtype)
+    for l in range(64):
+        g, i = l & ~15, l & 15
+        for q in range(4):
+            src = g + 4 * q + (i >> 2)
+            out[l, q] = mem[(addrs[src] + 2 * (i & 3)) // 2]
+    return out
+
+def dma_fill(tile):  # tile [rows][64] -> image, thread tid writes 16 B at 16*tid holding logical chunk (tid&7)^fsw(row)
+    rows = tile.shape[0]
+    mem = np.zeros(rows * 64, dtype=tile.dtype)
+    for tid in range(rows * 8):
+        row, pc = tid >> 3, tid & 7
+        c = pc ^ fsw(row)
+        mem[8 * tid:8 * tid + 8] = tile[row, 8 * c:8 * c + 8]
+    return mem
+
+rng = np.random.default_rng(0)
+conf = {}
+def note(name, addrs, width, groups, nbanks, ideal):
+    c = cyc(addrs, width, groups, nbanks)
+    conf.setdefault(name, [0, 0])
+    conf[name][0] += c
+    conf[name][1] += ideal
+
+# ================= image I1: a [64 q][64 d] tile (Q or dO) =================
+tile = rng.integers(1, 60000, size=(64, 64)).astype(np.uint16)
+mem = dma_fill(tile)
+lanes = np.arange(64)
+r, h = lanes & 31, lanes >> 5
+# (a) row read: A operand of S = Q.K^T: lane (r,h) holds A[row 32sub+r][k = 16s + 8h + j]
+B0 = r * 128 + ((h ^ np.array([fsw(x) for x in r])) << 4)
+for sub in range(2):
+    for s in range(4):
+        addr = (B0 ^ (s << 5)) + 4096 * sub
+        ref = np.array([off128(32 * sub + r[l], 2 * s + h[l]) for l in range(64)])
+        assert (addr == ref).all()
+        for l in range(64):
+            got = mem[addr[l] // 2: addr[l] // 2 + 8]
+            assert (got == tile[32 * sub + r[l], 16 * s + 8 * h[l]: 16 * s + 8 * h[l] + 8]).all()
+        note("I1 row b128", addr, 16, B128_GROUPS, 64, 4)
+# (b) transposed read: A operand of dV^T += dO^T.P: lane (r,h) holds A[row d = 32dt + r][k-slot (h,j)] with
+#     k-slot (h, j) of step s2 = q row 16 s2 + 8 (j>>2) + 4 h + (j&3) of the 32-row sub-tile
+rowL = 4 * (lanes >> 5) + ((lanes & 15) >> 2)
+chunkL = 2 * ((lanes >> 4) & 1) + ((lanes & 3) >> 1)
+halfL = 8 * (lanes & 1)
+A0 = rowL * 128 + ((chunkL ^ np.array([fsw(x) for x in rowL])) << 4) + halfL
+for sub in range(2):
+    for s2 in range(2):
+        for dt in range(2):
+            frag = np.zeros((64, 8), dtype=np.uint16)
+            for sec in range(2):
+                addr = (A0 ^ (0x30 * s2) ^ (0x20 * sec) ^ (0x40 * dt)) + 2048 * s2 + 1024 * sec + 4096 * sub
+                ref = np.array([off128(32 * sub + 16 * s2 + 8 * sec + rowL[l], 4 * dt + chunkL[l]) + halfL[l] for l in range(64)])
+                assert (addr == ref).all(), (sub, s2, dt, sec)
+                frag[:, 4 * sec:4 * sec + 4] = tr_read(mem, addr)
+                note("I1 tr b64", addr, 8, HALVES, 64, 2)
+            for l in range(64):
+                for j in range(8):
+                    q = 32 * sub + 16 * s2 + 8 * (j >> 2) + 4 * h[l] + (j & 3)
+                    assert frag[l, j] == tile[q, 32 * dt + r[l]], (l, j)
+# (c) delta: thread tid reads the 16 B at 16*tid = dO[row tid>>3][chunk (tid&7)^fsw(row)] (matches its O chunk from global)
+for w in range(8):
+    addr = 16 * (64 * w + lanes)
+    note("I1 delta b128", addr, 16, B128_GROUPS, 64, 4)
+
+# ================= image I2: K [256 keys][64 d], transposed read as the A operand of dQ^T = K^T.dS^T (16x16x32) =================
+K = rng.integers(1, 60000, size=(256, 64)).astype(np.uint16)
+memK = dma_fill(K)
+fq, i16 = lanes >> 4, lanes & 15
+rowK = 8 * fq + (i16 >> 2)
+K0 = rowK * 128 + ((((i16 & 3) >> 1) ^ np.array([fsw(x) for x in rowK])) << 4) + 8 * (i16 & 1)
+for kk in range(8):
+    for db in range(4):
+        frag = np.zeros((64, 8), dtype=np.uint16)
+        for sec in range(2):
+            addr = (K0 ^ (0x10 * sec) ^ (db << 5)) + 512 * sec + 4096 * kk
+            ref = np.array([off128(32 * kk + 8 * fq[l] + 4 * sec + (i16[l] >> 2), 2 * db + ((i16[l] & 3) >> 1)) + 8 * (i16[l] & 1) for l in range(64)])
+            assert (addr == ref).all(), (kk, db, sec)
+            frag[:, 4 * sec:4 * sec + 4] = tr_read(memK, addr)
+            note("I2 tr b64 (16x16x32 A)", addr, 8, HALVES, 64, 2)
+        for l in range(64):  # A[row = d = 16db + (l&15)][k = 8(l>>4) + j] = K[key 32kk + 8fq + j][d]
+            for j in range(8):
+                assert frag[l, j] == K[32 * kk + 8 * fq[l] + j, 16 * db + i16[l]]
+
+# ================= image I3: dS^T [256 keys][64 q] bf16, 8-byte slots =================
+dS = rng.integers(1, 60000, size=(64, 256)).astype(np.uint16)   # [q][key] as phase 1 holds it: key on the lane, q in registers
+memD = np.zeros(256 * 64, dtype=np.uint16)
+for w in range(8):
+    for sub in range(2):
+        for g4 in range(4):
+            key = 32 * w + r
+            slot = 8 * sub + 2 * g4 + h
+            addr = np.array([offds(key[l], slot[l]) for l in range(64)])
+            note("I3 ds_write_b64", addr, 8, W64, 32, 4)
+            for l in range(64):
+                q0 = 32 * sub + 8 * g4 + 4 * h[l]
+                memD[addr[l] // 2: addr[l] // 2 + 4] = dS[q0:q0 + 4, key[l]]
+rowD = 8 * fq + (i16 >> 2)
+for kk in range(8):
+    for qblk in range(4):
+        frag = np.zeros((64, 8), dtype=np.uint16)
+        for sec in range(2):
+            addr = np.array([offds(32 * kk + rowD[l] + 4 * sec, 4 * qblk + (i16[l] & 3)) for l in range(64)])
+            # closed form used by the kernel: base ^ (sec << 4) [Fsw bit1 = row bit 2] ^ (qblk << 5), + 512 sec + 4096 kk
+            D0 = rowD * 128 + (((i16 & 3) ^ np.array([Fsw(x) for x in rowD])) << 3)
+            assert (addr == (D0 ^ (sec << 4) ^ (qblk << 5)) + 512 * sec + 4096 * kk).all()
+            frag[:, 4 * sec:4 * sec + 4] = tr_read(memD, addr)
+            note("I3 tr b64 (16x16x32 B)", addr, 8, HALVES, 64, 2)
+        for l in range(64):  # B[k = 8(l>>4) + j][col = q = 16 qblk + (l&15)] = dS[q][key 32kk + 8fq + j]
+            for j in range(8):
+                assert frag[l, j] == dS[16 * qblk + i16[l], 32 * kk + 8 * fq[l] + j]
+
+# ================= dK / dV row staging of one wave: [32 keys][128 B], written as 8-byte pieces, read as 16-byte chunks =================
+X = rng.integers(1, 60000, size=(32, 64)).astype(np.uint16)
+memE = np.zeros(32 * 64, dtype=np.uint16)
+def offE(key, chunk):
+    return key * 128 + ((chunk ^ (key & 7)) << 4)
+for dt in range(2):
+    for g4 in range(4):
+        d0 = 32 * dt + 8 * g4 + 4 * h
+        addr = np.array([offE(r[l], d0[l] >> 3) + 2 * (d0[l] & 7) for l in range(64)])
+        note("E ds_write_b64", addr, 8, W64, 32, 4)
+        for l in range(64):
+            memE[addr[l] // 2: addr[l] // 2 + 4] = X[r[l], d0[l]:d0[l] + 4]
+for p in range(4):
+    key, ch = 8 * p + (lanes >> 3), lanes & 7
+    addr = np.array([offE(key[l], ch[l]) for l in range(64)])
+    note("E ds_read_b128", addr, 16, B128_GROUPS, 64, 4)
+    for l in range(64):
+        assert (memE[addr[l] // 2: addr[l] // 2 + 8] == X[key[l], 8 * ch[l]:8 * ch[l] + 8]).all()
+
+for k, (c, ideal) in conf.items():
+    print(f"{k:28s} LDS cycles {c:5d}  conflict-free {ideal:5d}  {'OK' if c == ideal else f'{c / ideal:.2f}x'}")
+print("fragment contents: all lane maps verified")

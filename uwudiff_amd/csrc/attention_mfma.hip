@@ -877,10 +877,16 @@ extern "C" int uwu_attention_rope_bwd(const void* q, const void* k, const void* 
   return UWU_OK;
 }
 
+bool uwu_attn_p256_fwd_ok(int T, int Tk, int d, int ldq, int ldk, int ldv, int ldo);
+int uwu_attn_p256_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int ldq, int ldk, int ldv,
+                      int ldo, float scale, hipStream_t st);
+
 int uwu_attn_mfma_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* kbias, int B,
                       int T, int Tk, int H, int d, int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t st) {
   UWU_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0,
                 "attention(mfma): q/k/v/o must be 16-byte aligned");
+  if (!kbias && uwu_attn_p256_fwd_ok(T, Tk, d, ldq, ldk, ldv, ldo))
+    return uwu_attn_p256_fwd(q, k, v, o, lse, B, H, ldq, ldk, ldv, ldo, scale, st);
   MArgs a{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)o; a.lse = lse;
   a.kbias = kbias;
@@ -892,6 +898,11 @@ int uwu_attn_mfma_fwd(const void* q, const void* k, const void* v, void* o, floa
   return UWU_OK;
 }
 
+// T = 256, head dim 64, no key bias: the persistent LDS-DMA kernel (attention_p256.hip)
+bool uwu_attn_p256_ok(int T, int Tk, int d, int ldq, int ldk, int ldv, int ldo);
+int uwu_attn_p256_bwd(const void* q, const void* k, const void* v, const void* o, const void* dO, const float* lse, void* dq,
+                      void* dk, void* dv, int B, int H, int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t st);
+
 int uwu_attn_mfma_bwd(const void* q, const void* k, const void* v, const void* o, const void* dO, const float* lse,
                       float* delta, const float* kbias, void* dq, void* dk, void* dv, int B, int T, int Tk, int H,
                       int d, int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t st) {
@@ -899,6 +910,8 @@ int uwu_attn_mfma_bwd(const void* q, const void* k, const void* v, const void* o
                   (uintptr_t)dk | (uintptr_t)dv) & 15) == 0,
                 "attention_bwd(mfma): tensors must be 16-byte aligned");
   (void)delta;  // the row sums of dO * O are formed inside the kernels
+  if (!kbias && uwu_attn_p256_ok(T, Tk, d, ldq, ldk, ldv, ldo))
+    return uwu_attn_p256_bwd(q, k, v, o, dO, lse, dq, dk, dv, B, H, ldq, ldk, ldv, ldo, scale, st);
   MArgs a{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o;
   a.dO = (const bf16_t*)dO; a.lse = const_cast<float*>(lse); a.delta = delta;

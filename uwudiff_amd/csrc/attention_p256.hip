@@ -1,0 +1,594 @@
+// Self-attention backward for T = 256 tokens, head dim 64 (every DiT shape at 256^2 latents): PERSISTENT workgroups that
+// stream heads through LDS-DMA rings.  Replaces F.scaled_dot_product_attention's backward (reference
+// src/duwu/modules/rope_unet.py:151-153) for that shape; the general kernels stay in attention_mfma.hip.
+//
+// Why a second kernel (measured on the one in attention_mfma.hip, B x H = 4608 heads: 452 us = 24.5 us per head and CU for
+// 4.3 us of MFMA work and 10.9 us of HBM time at the CU's share of 6 TB/s): one 8-wave workgroup per CU and head, operands
+// staged through registers one tile ahead -- every head pays its prologue (K^T image, K / V fragments, first tile: two dependent
+// HBM latencies), every tile a load latency the short compute phase cannot cover, and the workgroup's exit waits for the
+// dK / dV store drain.  249 VGPRs leave no room to prefetch further through registers, and two workgroups per CU do not fit
+// (128 KB of fp32 dK / dV accumulators per head).
+// Here a workgroup owns its CU for the whole launch and walks heads h = blockIdx.x, + gridDim.x, ...:
+//   * Q / dO tiles (64 query rows, 16 KB) arrive by LDS-DMA (global_load_lds_dwordx4: no VGPRs) into a ring of three slots,
+//     two tiles ahead and ACROSS head boundaries; the next head's K image (for dQ) and lse row arrive the same way, its K / V
+//     fragments are loaded straight into the fragment registers as soon as the last phase 1 of the current head has read them;
+//   * ONE row-major image per tile serves both uses of Q and dO: row reads (ds_read_b128) for S = Q.K^T, dP = dO.V^T and
+//     transposing reads (ds_read_b64_tr_b16) for dV^T += dO^T.P, dK^T += Q^T.dS -- no transposed copies, no staging VALU;
+//   * dS crosses LDS once, as a [key][q] image written with 8-byte stores (the accumulator holds 4 consecutive q per key) and
+//     read back with transposing reads as the B operand of dQ^T = K^T.dS^T; K^T comes from the row-major K image the same way;
+//   * dK / dV of a finished head are written while the next head's first tile is already in LDS; dq leaves as one 16-byte
+//     store per lane (v_permlane16_swap pairs two 4-column groups).
+// Image swizzles (16-byte chunks of 128-byte rows, 8-byte slots for dS^T) make every one of these accesses bank-conflict
+// free; tools/model_attn_lds.py checks the lane maps and the bank model on the host.
+// Vector-memory operations retire in issue order (loads, stores and LDS-DMA alike), so the only hand-counted wait is
+// `s_waitcnt vmcnt(1)` at the top of a tile: everything but the previous tile's dq store has landed.
+#include "common.h"
+
+namespace {
+
+constexpr int P_RING = 3, P_SLOT = 16384;          // Q tile (8 KB) | dO tile (8 KB)
+constexpr int P_OFF_DS = P_RING * P_SLOT;            // dS^T image [256 keys][64 q] bf16
+constexpr int P_OFF_K = P_OFF_DS + 32768;            // 2 x K image [256 keys][64 d] (head parity)
+constexpr int P_OFF_LSE = P_OFF_K + 2 * 32768;       // 2 x lse[256] fp32 (head parity)
+constexpr int P_OFF_DELTA = P_OFF_LSE + 2 * 1024;    // 2 x -delta[64] fp32 (tile parity)
+constexpr int P_LDS = P_OFF_DELTA + 2 * 256;         // 150016 B
+
+struct PArgs {
+  const bf16_t *q, *k, *v, *o, *dO;
+  bf16_t *dq, *dk, *dv;
+  const float* lse;
+  int B, H, ldq, ldk, ldv, ldo, nheads;
+  float scale;
+};
+
+// 16-byte chunk swizzle of the 128-byte-row images (Q / dO tiles, K image): bit0 = r2 ^ r4, bit1 = r3 ^ r4, bit2 = r1
+__device__ __forceinline__ int fsw(int row) {
+  return (((row >> 2) ^ (row >> 4)) & 1) | ((((row >> 3) ^ (row >> 4)) & 1) << 1) | (((row >> 1) & 1) << 2);
+}
+// 8-byte slot swizzle of the dS^T image: bit0 = r0, bit1 = r2, bit2 = r3, bit3 = r1
+__device__ __forceinline__ int Fsw(int row) {
+  return (row & 1) | (((row >> 2) & 1) << 1) | (((row >> 3) & 1) << 2) | (((row >> 1) & 1) << 3);
+}
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned su32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst /* wave-uniform */) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+__device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst /* wave-uniform */) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+__device__ __forceinline__ f32x16 mfma32(const uint4& a, const uint4& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b), c, 0,
+                                                 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16(const uint4& a, const uint4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b), c, 0,
+                                                 0, 0);
+}
+__device__ __forceinline__ uint4 pack8(const f32x16& x, int s) {
+  bf16x8 f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = (bf16_t)x[8 * s + j];
+  return *reinterpret_cast<uint4*>(&f);
+}
+
+extern __shared__ __attribute__((aligned(16))) char p_smem[];
+
+// lo = x of lane (l & 31), hi = x of lane (l & 31) + 32, in every lane: one v_permlane32_swap (lanes 32-63 of its first operand
+// trade places with lanes 0-31 of its second) instead of a trip through the LDS crossbar (__shfl_xor).  Inline asm: handed the
+// same value twice, the BUILTIN's two results came back folded into one register (hipcc, ROCm 7.2: max(x', x') of one half
+// only -- caught by the bit-identity test).  The two v_nop are the wait states between a VALU write and the permlane read.
+__device__ __forceinline__ void lane_halves(float x, float& lo, float& hi) {
+  float a = x, b = x;
+  asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  lo = a;
+  hi = b;
+}
+
+// two transposing reads (rows +0..3 of a block and the four rows behind a1) -> one 8-element MFMA operand fragment
+__device__ __forceinline__ uint4 tr_pair(unsigned a0, unsigned a1) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)((__attribute__((address_space(3))) char*)p_smem + a0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)((__attribute__((address_space(3))) char*)p_smem + a1));
+  uint4 r;
+  r.x = ((unsigned)(unsigned short)lo[0]) | ((unsigned)(unsigned short)lo[1] << 16);
+  r.y = ((unsigned)(unsigned short)lo[2]) | ((unsigned)(unsigned short)lo[3] << 16);
+  r.z = ((unsigned)(unsigned short)hi[0]) | ((unsigned)(unsigned short)hi[1] << 16);
+  r.w = ((unsigned)(unsigned short)hi[2]) | ((unsigned)(unsigned short)hi[3] << 16);
+  return r;
+}
+
+// ABL (tools only, UWU_P256_ABL): timing-only builds with wrong results -- 1: no dQ product, 2: no global stores, 4: no phase 1
+// (dS^T image left stale)
+template <int ABL>
+__global__ void __launch_bounds__(512, 2) attn_bwd_p256(const PArgs a) {
+  constexpr int T = 256, DH = 64;
+  char* const smem = p_smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int fr = lane & 15, fq = lane >> 4;
+  const unsigned smem_base = (unsigned)(size_t)((const __attribute__((address_space(3))) char*)p_smem);
+  const float c = a.scale * 1.4426950408889634f;
+  const float ninv_scale = -1.f / a.scale;
+  const int nmy = (a.nheads - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;  // heads of this workgroup
+  const int total = 4 * nmy;                                                             // its tiles
+  const int k0 = wave * 32;  // this wave's keys
+
+  // per-lane pieces of the LDS addresses (tools/model_attn_lds.py derives and checks them)
+  const int drow = tid >> 3;                             // DMA / delta: row of the 64-row tile this thread moves
+  const int dchunk = (tid & 7) ^ fsw(drow);              // ... and the logical 16-byte chunk that lands at LDS byte 16 * tid
+  const unsigned B0 = (unsigned)(r * 128 + ((h ^ fsw(r)) << 4));  // row read: chunk 2 s + h of row r
+  const int rowL = 4 * h + ((lane & 15) >> 2), chunkL = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);
+  const unsigned A0 = (unsigned)(rowL * 128 + ((chunkL ^ fsw(rowL)) << 4) + 8 * (lane & 1));  // transposing read of a Q / dO tile
+  const int rowK = 8 * fq + (fr >> 2);
+  const unsigned K0 = (unsigned)(rowK * 128 + ((((fr & 3) >> 1) ^ fsw(rowK)) << 4) + 8 * (fr & 1));  // ... of the K image
+  const unsigned D0 = (unsigned)(rowK * 128 + (((fr & 3) ^ Fsw(rowK)) << 3));                         // ... of the dS^T image
+
+  auto head_ptrs = [&](int j, int& b, int& hd) {
+    const int bh = (int)blockIdx.x + j * (int)gridDim.x;
+    b = bh / a.H;
+    hd = bh - b * a.H;
+  };
+  uint4 oreg;
+  // tile g = 4 j + t: rows 64 t .. 64 t + 63 of head j's Q and dO into ring slot g % 3; this thread's O chunk into oreg
+  auto issue_tile = [&](int g) {
+    int b, hd;
+    head_ptrs(g >> 2, b, hd);
+    const int row = 64 * (g & 3) + drow;
+    const bf16_t* qs = a.q + ((int64_t)b * T + row) * a.ldq + hd * DH + 8 * dchunk;
+    const bf16_t* gs = a.dO + ((int64_t)b * T + row) * a.ldo + hd * DH + 8 * dchunk;
+    const unsigned dst = smem_base + (unsigned)((g % P_RING) * P_SLOT + wave * 1024);
+    glds16(qs, dst);
+    glds16(gs, dst + 8192);
+    oreg = *reinterpret_cast<const uint4*>(a.o + ((int64_t)b * T + row) * a.ldo + hd * DH + 8 * dchunk);
+  };
+  // K image (4 pieces of 64 keys) and the lse row of head j
+  auto issue_head = [&](int j) {
+    int b, hd;
+    head_ptrs(j, b, hd);
+    const unsigned dst = smem_base + (unsigned)(P_OFF_K + (j & 1) * 32768 + wave * 1024);
+#pragma unroll
+    for (int p = 0; p < 4; ++p)  // (fsw only looks at row bits 1-4: the swizzle of row 64 p + drow is that of drow)
+      glds16(a.k + ((int64_t)b * T + 64 * p + drow) * a.ldk + hd * DH + 8 * dchunk, dst + p * 8192);
+    // 256 floats: waves w and w + 4 move the same 64 (equal instruction counts for every wave)
+    glds4(a.lse + ((int64_t)b * a.H + hd) * T + 64 * (wave & 3) + lane, smem_base + (unsigned)(P_OFF_LSE + (j & 1) * 1024 + (wave & 3) * 256));
+  };
+  uint4 kf[4], vf[4];
+  auto load_kv = [&](int j) {
+    int b, hd;
+    head_ptrs(j, b, hd);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      kf[s] = *reinterpret_cast<const uint4*>(a.k + ((int64_t)b * T + k0 + r) * a.ldk + hd * DH + 16 * s + 8 * h);
+      vf[s] = *reinterpret_cast<const uint4*>(a.v + ((int64_t)b * T + k0 + r) * a.ldv + hd * DH + 16 * s + 8 * h);
+    }
+  };
+  // -delta[q] = -sum_d dO[q][d] O[q][d] of tile g (its dO is in LDS, its O chunk in oreg): 8 lanes per row
+  auto delta_of = [&](int g) {
+    const uint4 gch = *reinterpret_cast<const uint4*>(smem + (g % P_RING) * P_SLOT + 8192 + 16 * tid);
+    const bf16x8 gv = *reinterpret_cast<const bf16x8*>(&gch), ov = *reinterpret_cast<const bf16x8*>(&oreg);
+    float ds = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ds += (float)gv[e] * (float)ov[e];
+    ds += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ds), 0xB1, 0xF, 0xF, true));   // lane ^ 1
+    ds += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ds), 0x4E, 0xF, 0xF, true));   // lane ^ 2
+    ds += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ds), 0x141, 0xF, 0xF, true));  // half-row mirror
+    if ((tid & 7) == 0) reinterpret_cast<float*>(smem + P_OFF_DELTA + (g & 1) * 256)[drow] = -ds;
+  };
+
+  f32x16 dkT[2], dvT[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt) dkT[dt] = dvT[dt] = f32x16{};
+
+  // dK / dV of head j: every wave passes its [32 keys][64 d] tiles through 4 KB of the K image buffer of that head (no longer
+  // read: the caller has passed a barrier behind the head's last dQ phase) and stores whole 128-byte rows
+  auto store_dkdv = [&](int j) {
+    int b, hd;
+    head_ptrs(j, b, hd);
+    char* mine = smem + P_OFF_K + (j & 1) * 32768 + wave * 4096;
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int d0 = 32 * dt + 8 * g4 + 4 * h;
+          const f32x16& x = which ? dvT[dt] : dkT[dt];
+          const float sc = which ? 1.f : a.scale;
+          store4(reinterpret_cast<bf16_t*>(mine + r * 128 + (((d0 >> 3) ^ (r & 7)) << 4) + 2 * (d0 & 7)),
+                 f32x4{x[4 * g4] * sc, x[4 * g4 + 1] * sc, x[4 * g4 + 2] * sc, x[4 * g4 + 3] * sc});
+        }
+      bf16_t* dst = (which ? a.dv : a.dk) + (int64_t)b * T * (which ? a.ldv : a.ldk) + hd * DH;
+      const int ld = which ? a.ldv : a.ldk;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {  // (same wave wrote and reads: no barrier; the compiler orders the LDS accesses)
+        const int key = 8 * p + (lane >> 3), ch = lane & 7;
+        const uint4 x = *reinterpret_cast<const uint4*>(mine + key * 128 + ((ch ^ (key & 7)) << 4));
+        if constexpr (!(ABL & 2)) *reinterpret_cast<uint4*>(dst + (int64_t)(k0 + key) * ld + 8 * ch) = x;
+        else asm volatile("" ::"v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w));
+      }
+    }
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) dkT[dt] = dvT[dt] = f32x16{};
+  };
+
+  // ---- prologue: head 0's K image / lse / fragments and tile 0, then tile 1 behind the first delta
+  if (total == 0) return;
+  issue_head(0);
+  issue_tile(0);
+  load_kv(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  delta_of(0);
+  if (1 < total) issue_tile(1);
+  // (hipcc puts no wait in front of a bare s_barrier: LDS writes that other waves read behind a barrier are drained by hand)
+
+  for (int g = 0; g < total; ++g) {
+    const int j = g >> 2, t = g & 3;
+    // [A] tile g + 1 (issued one iteration ago, with the K image / lse of its head if it opens one) has landed: every
+    // vector-memory operation of this wave except the youngest one -- the dq store of tile g - 1 -- is complete
+    if (g == 0 || (ABL & 3)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // [B] ... everybody's pieces; everybody has finished phase 2 of tile g - 1
+    if (t == 0 && j > 0) store_dkdv(j - 1);
+    if (g + 1 < total) delta_of(g + 1);                    // [D] consumes oreg (O chunk of tile g + 1)
+    if (g + 2 < total) {                                   // [C] ring slot (g + 2) % 3 was tile g - 1's
+      issue_tile(g + 2);
+      if (((g + 2) & 3) == 0) issue_head((g + 2) >> 2);
+    }
+    // ---- [E] phase 1: this wave's 32 keys against the 64 query rows of tile g
+    if constexpr (!(ABL & 4)) {
+      const unsigned Qs = (unsigned)((g % P_RING) * P_SLOT), Gs = Qs + 8192;
+      const float* ls = reinterpret_cast<const float*>(smem + P_OFF_LSE + (j & 1) * 1024) + 64 * t;
+      const float* dl = reinterpret_cast<const float*>(smem + P_OFF_DELTA + (g & 1) * 256);
+      char* const dsimg = smem + P_OFF_DS;
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        // row constants as the INITIAL accumulators: S' = Q.K^T - lse / scale, dP' = dO.V^T - delta
+        f32x16 S, dP;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x4 l4 = load4(ls + 32 * sub + 8 * g4 + 4 * h);
+          const f32x4 d4 = load4(dl + 32 * sub + 8 * g4 + 4 * h);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            S[4 * g4 + e] = l4[e] * ninv_scale;
+            dP[4 * g4 + e] = d4[e];
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const unsigned off = (B0 ^ (unsigned)(s << 5)) + 4096u * sub;
+          const uint4 qa = *reinterpret_cast<const uint4*>(smem + Qs + off);
+          const uint4 ga = *reinterpret_cast<const uint4*>(smem + Gs + off);
+          S = mfma32(qa, kf[s], S);
+          dP = mfma32(ga, vf[s], dP);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float p = __builtin_amdgcn_exp2f(S[i] * c);
+          S[i] = p;
+          dP[i] *= p;
+        }
+        // dS rounded to bf16 once: the pairs feed the [key][q] image (4 consecutive q per 8-byte store) and the dK operand
+        bf16x2 dsp[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) dsp[jj] = bf16x2{(bf16_t)dP[2 * jj], (bf16_t)dP[2 * jj + 1]};
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          uint2 w;
+          w.x = *reinterpret_cast<const unsigned*>(&dsp[2 * g4]);
+          w.y = *reinterpret_cast<const unsigned*>(&dsp[2 * g4 + 1]);
+          const int key = k0 + r;
+          *reinterpret_cast<uint2*>(dsimg + key * 128 + (((8 * sub + 2 * g4 + h) ^ Fsw(key)) << 3)) = w;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const uint4 pf = pack8(S, s2);
+          uint4 dsf;
+          dsf.x = *reinterpret_cast<const unsigned*>(&dsp[4 * s2]);
+          dsf.y = *reinterpret_cast<const unsigned*>(&dsp[4 * s2 + 1]);
+          dsf.z = *reinterpret_cast<const unsigned*>(&dsp[4 * s2 + 2]);
+          dsf.w = *reinterpret_cast<const unsigned*>(&dsp[4 * s2 + 3]);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const unsigned x0 = (A0 ^ (unsigned)(0x30 * s2) ^ (unsigned)(0x40 * dt)) + 2048u * s2 + 4096u * sub;
+            const unsigned x1 = (x0 ^ 0x20u) + 1024u;
+            const uint4 gt = tr_pair(Gs + x0, Gs + x1);
+            const uint4 qt = tr_pair(Qs + x0, Qs + x1);
+            dvT[dt] = mfma32(gt, pf, dvT[dt]);
+            dkT[dt] = mfma32(qt, dsf, dkT[dt]);
+          }
+        }
+      }
+    }
+    // the K / V fragments are dead until the next head's first phase 1: load its rows now, under phase 2 and the stores
+    if (t == 3 && j + 1 < nmy) load_kv(j + 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's dS^T (and delta) writes have reached LDS
+    __builtin_amdgcn_s_barrier();                       // [F] dS^T image complete
+    // ---- [G] phase 2: dQ^T[d][q] = K^T[d][key] . dS^T[key][q]; wave w owns q-block w & 3 and d-blocks 2 (w >> 2), + 1
+    if constexpr (!(ABL & 1)) {
+      const int qblk = wave & 3, db0 = 2 * (wave >> 2);
+      const unsigned Ki = (unsigned)(P_OFF_K + (j & 1) * 32768), Di = (unsigned)P_OFF_DS;
+      const unsigned ka = K0 ^ (unsigned)(db0 << 5), kb = K0 ^ (unsigned)((db0 + 1) << 5), da = D0 ^ (unsigned)(qblk << 5);
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const unsigned ko = 4096u * kk;
+        const uint4 fa = tr_pair(Ki + ka + ko, Ki + (ka ^ 0x10u) + 512u + ko);
+        const uint4 fb = tr_pair(Ki + kb + ko, Ki + (kb ^ 0x10u) + 512u + ko);
+        const uint4 fd = tr_pair(Di + da + ko, Di + (da ^ 0x10u) + 512u + ko);
+        acc0 = mfma16(fa, fd, acc0);
+        acc1 = mfma16(fb, fd, acc1);
+      }
+      // D[row = d = 16 db + 4 fq + reg][col = q = fr]: the lane holds 4 consecutive d of both d-blocks of one query row.
+      // v_permlane16_swap pairs fq with fq ^ 1: even fq keeps d-block db0 (8 consecutive d), odd fq takes d-block db0 + 1
+      int b, hd;
+      head_ptrs(j, b, hd);
+      const f32x4 v0 = acc0 * a.scale, v1 = acc1 * a.scale;
+      const bf16x4 p0b = {(bf16_t)v0[0], (bf16_t)v0[1], (bf16_t)v0[2], (bf16_t)v0[3]};
+      const bf16x4 p1b = {(bf16_t)v1[0], (bf16_t)v1[1], (bf16_t)v1[2], (bf16_t)v1[3]};
+      const uint2 p0 = *reinterpret_cast<const uint2*>(&p0b), p1 = *reinterpret_cast<const uint2*>(&p1b);
+      const su32x2 sx = __builtin_amdgcn_permlane16_swap(p0.x, p1.x, false, false);
+      const su32x2 sy = __builtin_amdgcn_permlane16_swap(p0.y, p1.y, false, false);
+      const bool odd = fq & 1;
+      const int d = odd ? 16 * (db0 + 1) + 4 * (fq - 1) : 16 * db0 + 4 * fq;
+      bf16_t* dst = a.dq + ((int64_t)b * T + 64 * t + 16 * qblk + fr) * a.ldq + hd * DH + d;
+      if constexpr (!(ABL & 2)) *reinterpret_cast<uint4*>(dst) = uint4{sx[0], sy[0], sx[1], sy[1]};
+      else asm volatile("" ::"v"(sx[0]), "v"(sy[0]), "v"(sx[1]), "v"(sy[1]), "v"(dst));
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // every wave has finished the last dQ phase: the K image buffer is free
+  store_dkdv(nmy - 1);
+}
+
+// ------------------------------------------------------------------------------------------- forward
+// Same machinery: a workgroup = 8 waves x 32 query rows = one whole head; K / V tiles of 64 keys (8 KB + 8 KB, row-major,
+// swizzled by the DMA's source addresses) stream through a ring of F_RING slots, F_RING - 1 tiles ahead and across head
+// boundaries; S^T = K.Q^T from row reads, O^T += V^T.P^T with V^T gathered by transposing reads (the k-slot permutation of the
+// accumulator -> operand reuse is the one the reads' row order already has).  One barrier per tile.  The next head's Q
+// fragments are loaded into a second register set two tiles before they are needed; O leaves through a wave-private 4 KB LDS
+// stage as whole 128-byte rows.  The arithmetic per output element is the sequence of the kernel in attention_mfma.hip.
+constexpr int F_RING = 6, F_SLOT = 16384;
+constexpr int F_OFF_O = F_RING * F_SLOT;   // 8 x 4 KB: per-wave O stage
+constexpr int F_LDS = F_OFF_O + 8 * 4096;  // 131072 B
+
+struct FArgs {
+  const bf16_t *q, *k, *v;
+  bf16_t* out;
+  float* lse;
+  int B, H, ldq, ldk, ldv, ldo, nheads;
+  float scale;
+};
+
+__global__ void __launch_bounds__(512, 2) attn_fwd_p256(const FArgs a) {
+  constexpr int T = 256, DH = 64;
+  char* const smem = p_smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const unsigned smem_base = (unsigned)(size_t)((const __attribute__((address_space(3))) char*)p_smem);
+  const float c = a.scale * 1.4426950408889634f;
+  const int nmy = (a.nheads - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int total = 4 * nmy;
+  const int q0 = wave * 32;
+  const int drow = tid >> 3;
+  const int dchunk = (tid & 7) ^ fsw(drow);
+  const unsigned B0 = (unsigned)(r * 128 + ((h ^ fsw(r)) << 4));
+  const int rowL = 4 * h + ((lane & 15) >> 2), chunkL = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);
+  const unsigned A0 = (unsigned)(rowL * 128 + ((chunkL ^ fsw(rowL)) << 4) + 8 * (lane & 1));
+  auto head_ptrs = [&](int j, int& b, int& hd) {
+    const int bh = (int)blockIdx.x + j * (int)gridDim.x;
+    b = bh / a.H;
+    hd = bh - b * a.H;
+  };
+  auto issue_tile = [&](int g) {  // keys 64 t .. 64 t + 63 of head j: K tile | V tile into slot g % F_RING
+    int b, hd;
+    head_ptrs(g >> 2, b, hd);
+    const int row = 64 * (g & 3) + drow;
+    const unsigned dst = smem_base + (unsigned)((g % F_RING) * F_SLOT + wave * 1024);
+    glds16(a.k + ((int64_t)b * T + row) * a.ldk + hd * DH + 8 * dchunk, dst);
+    glds16(a.v + ((int64_t)b * T + row) * a.ldv + hd * DH + 8 * dchunk, dst + 8192);
+  };
+  uint4 qf[4], qn[4];
+  auto load_q = [&](uint4 (&dst)[4], int j) {
+    int b, hd;
+    head_ptrs(j, b, hd);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      dst[s] = *reinterpret_cast<const uint4*>(a.q + ((int64_t)b * T + q0 + r) * a.ldq + hd * DH + 16 * s + 8 * h);
+  };
+  if (total == 0) return;
+  load_q(qf, 0);
+#pragma unroll
+  for (int g = 0; g < F_RING - 1; ++g)
+    if (g < total) issue_tile(g);
+
+  f32x16 o[2];
+  float m = -INFINITY, l = 0.f;
+  for (int g = 0; g < total; ++g) {
+    const int j = g >> 2, t = g & 3;
+    // tile g has landed: of this wave's vector-memory operations only the DMA of the F_RING - 2 tiles behind it (2 each)
+    // may still be in flight -- anything else issued since (O / lse stores, Q loads) is younger still and only makes the wait
+    // stronger.  The last tiles of the launch have fewer tiles behind them: full wait.
+    if (g + F_RING - 2 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (F_RING - 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // everybody's pieces of tile g; everybody has finished reading tile g - 1
+    if (g + F_RING - 1 < total) issue_tile(g + F_RING - 1);  // into tile g - 1's slot
+    if (t == 0) {
+      if (j > 0) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = qn[s];
+      }
+      o[0] = o[1] = f32x16{};
+      m = -INFINITY;
+      l = 0.f;
+    }
+    if (t == 1 && j + 1 < nmy) load_q(qn, j + 1);
+    const unsigned Ks = (unsigned)((g % F_RING) * F_SLOT), Vs = Ks + 8192;
+    f32x16 s[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      s[kt] = f32x16{};
+#pragma unroll
+      for (int ss = 0; ss < 4; ++ss) {
+        const uint4 kfr = *reinterpret_cast<const uint4*>(smem + Ks + (B0 ^ (unsigned)(ss << 5)) + 4096u * kt);
+        s[kt] = mfma32(kfr, qf[ss], s[kt]);
+      }
+    }
+    float mx = s[0][0];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[kt][i]);
+    {  // the other lane half holds the other 32 keys of the row
+      float lo, hi;
+      lane_halves(mx, lo, hi);
+      mx = fmaxf(lo, hi);
+    }
+    const float mn = fmaxf(m, mx);
+    const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);
+    const float mc = mn * c;
+    float ls = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float p = __builtin_amdgcn_exp2f(s[kt][i] * c - mc);
+        s[kt][i] = p;
+        ls += p;
+      }
+    l = l * alpha + ls;
+    m = mn;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const uint4 pf = pack8(s[kt], s2);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const unsigned x0 = (A0 ^ (unsigned)(0x30 * s2) ^ (unsigned)(0x40 * dt)) + 2048u * s2 + 4096u * kt;
+          const uint4 vt = tr_pair(Vs + x0, Vs + (x0 ^ 0x20u) + 1024u);
+          o[dt] = mfma32(vt, pf, o[dt]);
+        }
+      }
+    if (t == 3) {  // the head is complete: O / l through the wave's LDS stage as whole rows, lse
+      int b, hd;
+      head_ptrs(j, b, hd);
+      float lt;
+      {
+        float lo, hi;
+        lane_halves(l, lo, hi);
+        lt = lo + hi;
+      }
+      const float inv = 1.f / lt;
+      char* mine = smem + F_OFF_O + wave * 4096;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int d0 = 32 * dt + 8 * g4 + 4 * h;
+          store4(reinterpret_cast<bf16_t*>(mine + r * 128 + (((d0 >> 3) ^ (r & 7)) << 4) + 2 * (d0 & 7)),
+                 f32x4{o[dt][4 * g4] * inv, o[dt][4 * g4 + 1] * inv, o[dt][4 * g4 + 2] * inv, o[dt][4 * g4 + 3] * inv});
+        }
+      bf16_t* ob = a.out + ((int64_t)b * T + q0) * a.ldo + hd * DH;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {  // (same wave wrote and reads: no barrier)
+        const int row = 8 * p + (lane >> 3), ch = lane & 7;
+        const uint4 x = *reinterpret_cast<const uint4*>(mine + row * 128 + ((ch ^ (row & 7)) << 4));
+        *reinterpret_cast<uint4*>(ob + (int64_t)row * a.ldo + 8 * ch) = x;
+      }
+      if (h == 0) a.lse[((int64_t)b * a.H + hd) * T + q0 + r] = m * a.scale + __logf(lt);
+    }
+  }
+}
+
+}  // namespace
+
+bool uwu_attn_p256_ok(int T, int Tk, int d, int ldq, int ldk, int ldv, int ldo) {
+  static UwuEnv on("UWU_ATTN_P256");  // "0": the one-workgroup-per-head kernel of attention_mfma.hip (A/B comparisons)
+  return !on.get().is('0') && T == 256 && Tk == 256 && d == 64 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0;
+}
+
+int uwu_attn_p256_bwd(const void* q, const void* k, const void* v, const void* o, const void* dO, const float* lse, void* dq,
+                      void* dk, void* dv, int B, int H, int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t st) {
+  static int n_cu = 0;
+  static bool once = false;
+  if (!once) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+      uwu_set_error("attention_bwd(p256): cannot query the device");
+      return UWU_ELAUNCH;
+    }
+    n_cu = prop.multiProcessorCount;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_p256<0>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_p256<1>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_p256<2>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_p256<3>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_p256<4>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+    once = true;
+  }
+  PArgs a{};
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o; a.dO = (const bf16_t*)dO;
+  a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.lse = lse;
+  a.B = B; a.H = H; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.nheads = B * H; a.scale = scale;
+  // one workgroup per CU (150 KB of LDS each); every workgroup exits after its last head -- no inter-workgroup waits
+  const int grid = a.nheads < n_cu ? a.nheads : n_cu;
+  static UwuEnv abl("UWU_P256_ABL");  // timing-only ablations / stamps (tools/bench_attn.py); results are wrong with them
+  switch (abl.get().ival) {
+    case 1: hipLaunchKernelGGL(attn_bwd_p256<1>, dim3(grid), dim3(512), P_LDS, st, a); break;
+    case 2: hipLaunchKernelGGL(attn_bwd_p256<2>, dim3(grid), dim3(512), P_LDS, st, a); break;
+    case 3: hipLaunchKernelGGL(attn_bwd_p256<3>, dim3(grid), dim3(512), P_LDS, st, a); break;
+    case 4: hipLaunchKernelGGL(attn_bwd_p256<4>, dim3(grid), dim3(512), P_LDS, st, a); break;
+    default: hipLaunchKernelGGL(attn_bwd_p256<0>, dim3(grid), dim3(512), P_LDS, st, a);
+  }
+  UWU_LAUNCH_CHECK("attention_bwd(p256)");
+  return UWU_OK;
+}
+
+bool uwu_attn_p256_fwd_ok(int T, int Tk, int d, int ldq, int ldk, int ldv, int ldo) {
+  static UwuEnv on("UWU_ATTN_P256F");  // "0": the kernel of attention_mfma.hip (A/B comparisons)
+  return !on.get().is('0') && T == 256 && Tk == 256 && d == 64 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0;
+}
+
+int uwu_attn_p256_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int ldq, int ldk, int ldv,
+                      int ldo, float scale, hipStream_t st) {
+  static int n_cu = 0;
+  static bool once = false;
+  if (!once) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+      uwu_set_error("attention_fwd(p256): cannot query the device");
+      return UWU_ELAUNCH;
+    }
+    n_cu = prop.multiProcessorCount;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_p256), hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
+    once = true;
+  }
+  FArgs a{};
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)o; a.lse = lse;
+  a.B = B; a.H = H; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.nheads = B * H; a.scale = scale;
+  const int grid = a.nheads < n_cu ? a.nheads : n_cu;
+  hipLaunchKernelGGL(attn_fwd_p256, dim3(grid), dim3(512), F_LDS, st, a);
+  UWU_LAUNCH_CHECK("attention_fwd(p256)");
+  return UWU_OK;
+}
