@@ -229,18 +229,25 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_p256(const PArgs a) {
   issue_head(0);
   issue_tile(0);
   load_kv(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // The waits are the BUILTIN (s_waitcnt immediates: vmcnt in bits 3:0, expcnt 6:4 = 7 "no wait", lgkmcnt 11:8): hipcc's own
+  // wait-count pass sees them and learns that the K / V fragment loads and the O chunk -- ordinary loads it tracks, all older
+  // than the one operation left in flight -- have landed.  With inline-asm waits it did not know, and put vmcnt(7) .. vmcnt(0)
+  // in front of the first S / dP MFMAs of EVERY tile: a full drain of the DMA ring just issued (the LDS-DMA itself stays inline
+  // asm: hipcc must not count it, or it would drain it before every LDS read).
+  __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
+  asm volatile("" ::: "memory");
   __builtin_amdgcn_s_barrier();
   delta_of(0);
   if (1 < total) issue_tile(1);
   // (hipcc puts no wait in front of a bare s_barrier: LDS writes that other waves read behind a barrier are drained by hand)
-
+  __builtin_amdgcn_s_waitcnt(0x0070);  // tile 1: nothing younger to leave in flight yet (and the loop's wait is unconditional:
+                                       // behind a branch the wait-count pass assumes the path around it)
   for (int g = 0; g < total; ++g) {
     const int j = g >> 2, t = g & 3;
     // [A] tile g + 1 (issued one iteration ago, with the K image / lse of its head if it opens one) has landed: every
     // vector-memory operation of this wave except the youngest one -- the dq store of tile g - 1 -- is complete
-    if (g == 0 || (ABL & 3)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt((ABL & 3) ? 0x0070 : 0x0071);  // vmcnt(1) lgkmcnt(0)  (timing builds without that store: vmcnt(0))
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();  // [B] ... everybody's pieces; everybody has finished phase 2 of tile g - 1
     if (t == 0 && j > 0) store_dkdv(j - 1);
     if (g + 1 < total) delta_of(g + 1);                    // [D] consumes oreg (O chunk of tile g + 1)
