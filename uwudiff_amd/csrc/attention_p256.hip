@@ -67,6 +67,15 @@ __device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst /* wave
                : "v"(gsrc), "s"(lds_dst)
                : "memory");
 }
+// the same with the address split into a wave-uniform base (SGPR pair) and a 32-bit per-lane byte offset: the per-tile address
+// arithmetic shrinks to one v_add_u32 (the 64-bit per-lane pointers cost ~25 VALU + ~80 SALU instructions per tile)
+__device__ __forceinline__ void glds16_s(const void* sbase /* wave-uniform */, unsigned voff, unsigned lds_dst /* wave-uniform */) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory");
+}
 __device__ __forceinline__ f32x16 mfma32(const uint4& a, const uint4& b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b), c, 0,
                                                  0, 0);
@@ -366,12 +375,16 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_p256(const PArgs a) {
 // Same machinery: a workgroup = 8 waves x 32 query rows = one whole head; K / V tiles of 64 keys (8 KB + 8 KB, row-major,
 // swizzled by the DMA's source addresses) stream through a ring of F_RING slots, F_RING - 1 tiles ahead and across head
 // boundaries; S^T = K.Q^T from row reads, O^T += V^T.P^T with V^T gathered by transposing reads (the k-slot permutation of the
-// accumulator -> operand reuse is the one the reads' row order already has).  One barrier per tile.  The next head's Q
-// fragments are loaded into a second register set two tiles before they are needed; O leaves through a wave-private 4 KB LDS
-// stage as whole 128-byte rows.  The arithmetic per output element is the sequence of the kernel in attention_mfma.hip.
-constexpr int F_RING = 6, F_SLOT = 16384;
-constexpr int F_OFF_O = F_RING * F_SLOT;   // 8 x 4 KB: per-wave O stage
-constexpr int F_LDS = F_OFF_O + 8 * 4096;  // 131072 B
+// accumulator -> operand reuse is the one the reads' row order already has).  One barrier per tile.  Q arrives by LDS-DMA too
+// (the next head's 32 KB image three tiles before it is needed; a wave reads its fragments from it once per head): with
+// ordinary global loads for Q, hipcc's wait-count pass put vmcnt(3) .. vmcnt(0) in front of the S MFMAs of every tile and
+// drained the ring.  The kernel has NO load the compiler tracks; every wait is hand-counted (younger()).  O leaves through a
+// wave-private 4 KB LDS stage as whole 128-byte rows.  The arithmetic per output element is the sequence of the kernel in
+// attention_mfma.hip (bit-identical results).
+constexpr int F_RING = 5, F_SLOT = 16384;
+constexpr int F_OFF_O = F_RING * F_SLOT;      // 8 x 4 KB: per-wave O stage
+constexpr int F_OFF_Q = F_OFF_O + 8 * 4096;   // Q image [256 q][64 d] of the head in flight (then of the next one)
+constexpr int F_LDS = F_OFF_Q + 32768;        // 147456 B
 
 struct FArgs {
   const bf16_t *q, *k, *v;
@@ -380,6 +393,32 @@ struct FArgs {
   int B, H, ldq, ldk, ldv, ldo, nheads;
   float scale;
 };
+
+template <int N>
+__device__ __forceinline__ void wait_vm_n() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// wait until at most n (wave-uniform, 0 .. 15+) of this wave's vector-memory operations are in flight
+__device__ __forceinline__ void wait_vm(int n) {
+  switch (n < 15 ? n : 15) {
+    case 15: wait_vm_n<15>(); break;
+    case 14: wait_vm_n<14>(); break;
+    case 13: wait_vm_n<13>(); break;
+    case 12: wait_vm_n<12>(); break;
+    case 11: wait_vm_n<11>(); break;
+    case 10: wait_vm_n<10>(); break;
+    case 9: wait_vm_n<9>(); break;
+    case 8: wait_vm_n<8>(); break;
+    case 7: wait_vm_n<7>(); break;
+    case 6: wait_vm_n<6>(); break;
+    case 5: wait_vm_n<5>(); break;
+    case 4: wait_vm_n<4>(); break;
+    case 3: wait_vm_n<3>(); break;
+    case 2: wait_vm_n<2>(); break;
+    case 1: wait_vm_n<1>(); break;
+    default: wait_vm_n<0>();
+  }
+}
 
 __global__ void __launch_bounds__(512, 2) attn_fwd_p256(const FArgs a) {
   constexpr int T = 256, DH = 64;
@@ -395,6 +434,7 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_p256(const FArgs a) {
   const int drow = tid >> 3;
   const int dchunk = (tid & 7) ^ fsw(drow);
   const unsigned B0 = (unsigned)(r * 128 + ((h ^ fsw(r)) << 4));
+  const unsigned QR0 = (unsigned)(F_OFF_Q + (q0 + r) * 128 + ((h ^ fsw(q0 + r)) << 4));  // chunk 2 s + h of query row q0 + r
   const int rowL = 4 * h + ((lane & 15) >> 2), chunkL = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);
   const unsigned A0 = (unsigned)(rowL * 128 + ((chunkL ^ fsw(rowL)) << 4) + 8 * (lane & 1));
   auto head_ptrs = [&](int j, int& b, int& hd) {
@@ -402,49 +442,80 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_p256(const FArgs a) {
     b = bh / a.H;
     hd = bh - b * a.H;
   };
-  auto issue_tile = [&](int g) {  // keys 64 t .. 64 t + 63 of head j: K tile | V tile into slot g % F_RING
-    int b, hd;
-    head_ptrs(g >> 2, b, hd);
-    const int row = 64 * (g & 3) + drow;
-    const unsigned dst = smem_base + (unsigned)((g % F_RING) * F_SLOT + wave * 1024);
-    glds16(a.k + ((int64_t)b * T + row) * a.ldk + hd * DH + 8 * dchunk, dst);
-    glds16(a.v + ((int64_t)b * T + row) * a.ldv + hd * DH + 8 * dchunk, dst + 8192);
-  };
-  uint4 qf[4], qn[4];
-  auto load_q = [&](uint4 (&dst)[4], int j) {
+  // per-lane byte offsets of this thread's DMA pieces inside a head's [256][ld] slab (row drow, 16-byte chunk dchunk) and
+  // wave-uniform slab bases: every workgroup walks heads blockIdx.x, + gridDim.x, ...
+  const unsigned kvoff = (unsigned)((drow * a.ldk + 8 * dchunk) * 2), vvoff = (unsigned)((drow * a.ldv + 8 * dchunk) * 2);
+  const unsigned qvoff = (unsigned)((drow * a.ldq + 8 * dchunk) * 2);
+  const bf16_t *kb_n = nullptr, *vb_n = nullptr, *qb_n = nullptr;  // slabs of the head whose tiles are being issued
+  int b_c = 0, hd_c = 0;                                             // (batch, head) of the head being computed
+  auto set_issue_head = [&](int j) {
     int b, hd;
     head_ptrs(j, b, hd);
+    kb_n = a.k + (int64_t)b * T * a.ldk + hd * DH;
+    vb_n = a.v + (int64_t)b * T * a.ldv + hd * DH;
+    qb_n = a.q + (int64_t)b * T * a.ldq + hd * DH;
+  };
+  auto issue_tile = [&](int g) {  // keys 64 t .. 64 t + 63 of the issue head: K tile | V tile into slot g % F_RING  (2 operations)
+    const int t64 = 64 * (g & 3);
+    const unsigned dst = smem_base + (unsigned)((g % F_RING) * F_SLOT + wave * 1024);
+    glds16_s(kb_n, kvoff + (unsigned)(t64 * a.ldk * 2), dst);
+    glds16_s(vb_n, vvoff + (unsigned)(t64 * a.ldv * 2), dst + 8192);
+  };
+  auto issue_q = [&]() {  // Q image of the issue head  (4 operations)
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
-      dst[s] = *reinterpret_cast<const uint4*>(a.q + ((int64_t)b * T + q0 + r) * a.ldq + hd * DH + 16 * s + 8 * h);
+    for (int p = 0; p < 4; ++p)
+      glds16_s(qb_n, qvoff + (unsigned)(64 * p * a.ldq * 2), smem_base + (unsigned)(F_OFF_Q + p * 8192 + wave * 1024));
+  };
+  // What a wave issues behind the DMA of tile i, inside iteration i's body: the next head's Q image (t == 1: 4 operations),
+  // the head's O rows and lse (t == 3: 4 + 1 stores)
+  auto extras = [&](int i) { return ((i & 3) == 1 && (i >> 2) + 1 < nmy ? 4 : 0) + ((i & 3) == 3 ? 5 : 0); };
+  // vector-memory operations of this wave that are YOUNGER than the DMA of tile g when iteration g begins: tile g's DMA was
+  // issued in iteration g - (F_RING - 1) (or in the prologue, with the tiles behind it), everything since is in issue order
+  auto younger = [&](int g) {
+    int y = 0;
+    const int gi = g - (F_RING - 1);  // issuing iteration
+    if (gi < 0) {
+      for (int x = g + 1; x < F_RING - 1; ++x) y += x < total ? 2 : 0;  // the prologue's tiles behind it
+    } else {
+      y += extras(gi);
+    }
+    for (int i = gi < 0 ? 0 : gi + 1; i < g; ++i) y += (i + F_RING - 1 < total ? 2 : 0) + extras(i);
+    return y;
   };
   if (total == 0) return;
-  load_q(qf, 0);
+  static_assert(F_RING - 1 == 4, "the tiles issued in iteration g belong to the head after the one being computed");
+  set_issue_head(0);
+  head_ptrs(0, b_c, hd_c);
+  issue_q();
 #pragma unroll
-  for (int g = 0; g < F_RING - 1; ++g)
-    if (g < total) issue_tile(g);
+  for (int g = 0; g < F_RING - 1; ++g) issue_tile(g);  // (total >= 4)
 
+  uint4 qf[4];
   f32x16 o[2];
   float m = -INFINITY, l = 0.f;
   for (int g = 0; g < total; ++g) {
     const int j = g >> 2, t = g & 3;
-    // tile g has landed: of this wave's vector-memory operations only the DMA of the F_RING - 2 tiles behind it (2 each)
-    // may still be in flight -- anything else issued since (O / lse stores, Q loads) is younger still and only makes the wait
-    // stronger.  The last tiles of the launch have fewer tiles behind them: full wait.
-    if (g + F_RING - 2 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (F_RING - 2)) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // everybody's pieces of tile g; everybody has finished reading tile g - 1
+    int n_fly = younger(g);  // tile g has landed when at most this many operations are in flight
+    if (t == 0 && j > 0) {   // ... and the head's Q image, issued one iteration AFTER its first tile (in iteration g - 3, behind
+      // that iteration's tile): younger than it are the tiles of iterations g - 2 and g - 1 and the previous head's 5 stores
+      const int yq = (g - 2 + F_RING - 1 < total ? 2 : 0) + (g - 1 + F_RING - 1 < total ? 2 : 0) + 5;
+      n_fly = yq < n_fly ? yq : n_fly;
+    }
+    wait_vm(n_fly);
+    __builtin_amdgcn_s_barrier();  // ... everybody's pieces; everybody has finished reading tile g - 1
+    if (t == 0) {
+      head_ptrs(j, b_c, hd_c);
+      if (j + 1 < nmy) set_issue_head(j + 1);  // tiles g + 4 .. g + 7 and the Q image issued at t == 1 are the next head's
+    }
     if (g + F_RING - 1 < total) issue_tile(g + F_RING - 1);  // into tile g - 1's slot
     if (t == 0) {
-      if (j > 0) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) qf[s] = qn[s];
-      }
+      for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const uint4*>(smem + (QR0 ^ (unsigned)(s << 5)));
       o[0] = o[1] = f32x16{};
       m = -INFINITY;
       l = 0.f;
     }
-    if (t == 1 && j + 1 < nmy) load_q(qn, j + 1);
+    if (t == 1 && j + 1 < nmy) issue_q();  // every wave has its fragments (read before this iteration's barrier)
     const unsigned Ks = (unsigned)((g % F_RING) * F_SLOT), Vs = Ks + 8192;
     f32x16 s[2];
 #pragma unroll
@@ -496,9 +567,8 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_p256(const FArgs a) {
           o[dt] = mfma32(vt, pf, o[dt]);
         }
       }
-    if (t == 3) {  // the head is complete: O / l through the wave's LDS stage as whole rows, lse
-      int b, hd;
-      head_ptrs(j, b, hd);
+    if (t == 3) {  // the head is complete: O / l through the wave's LDS stage as whole rows, lse  (4 + 1 stores: extras())
+      const int b = b_c, hd = hd_c;
       float lt;
       {
         float lo, hi;
@@ -522,7 +592,9 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_p256(const FArgs a) {
         const uint4 x = *reinterpret_cast<const uint4*>(mine + row * 128 + ((ch ^ (row & 7)) << 4));
         *reinterpret_cast<uint4*>(ob + (int64_t)row * a.ldo + 8 * ch) = x;
       }
-      if (h == 0) a.lse[((int64_t)b * a.H + hd) * T + q0 + r] = m * a.scale + __logf(lt);
+      // (every lane stores: lanes r and r + 32 write the same value to the same address -- one store INSTRUCTION either way,
+      // which is what the hand-counted waits count)
+      a.lse[((int64_t)b * a.H + hd) * T + q0 + r] = m * a.scale + __logf(lt);
     }
   }
 }
