@@ -63,6 +63,48 @@ def test_add_ln_modulate_fwd_bwd(D, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("D,B,T,with_y,affine", [(384, 17, 256, True, False), (768, 16, 259, True, False), (1152, 5, 1000, False, False),
+                                                  (128, 33, 128, True, False), (1280, 4, 1027, False, True)])
+def test_add_ln_modulate_fwd_four_rows_per_wave(D, B, T, with_y, affine, dtype, monkeypatch):
+    """M >= 4096 rows, D a multiple of 128: the forward kernel that gives a row to 16 lanes (four rows per wave, DPP row sums).
+    Against the fp32 reference, and against the one-row-per-wave kernel (UWU_LN_ROW16=0) on the same inputs -- the token
+    counts make row groups straddle samples and leave a ragged last group (B * T not a multiple of 16)."""
+    from uwudiff_amd import ops
+
+    torch.manual_seed(3)
+    M, ML = B * T, 3 * D + 8
+    x_in = torch.randn(M, D).to(dtype)
+    y = torch.randn(M, D).to(dtype) if with_y else None
+    mod = torch.randn(1 if affine else B, ML) * 0.5
+    md = mod.cuda()
+    g, sh, sc = md[:, 0:D], md[:, D:2 * D], md[:, 2 * D:3 * D]
+    rep = (lambda v: v.expand(B, -1).repeat_interleave(T, 0)) if affine else (lambda v: v.repeat_interleave(T, 0))
+    xo = x_in.float()
+    if with_y:
+        xo = xo + rep(mod[:, 0:D]) * y.float()
+        if dtype == torch.bfloat16:
+            xo = xo.bfloat16().float()
+    sc_r, sh_r = rep(mod[:, 2 * D:3 * D]), rep(mod[:, D:2 * D])
+    hr = F.layer_norm(xo, (D,), eps=1e-6) * (sc_r if affine else 1 + sc_r) + sh_r
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("UWU_LN_ROW16", flag)
+        kw = dict(shift=sh, scale=sc, mod_ld=0 if affine else ML, affine=affine)
+        if with_y:
+            kw.update(y=y.cuda(), gate=g)
+        outs[flag] = ops.add_ln_modulate_fwd(x_in.cuda(), B, T, **kw)
+    x_out, h, mean, rstd = outs["1"]
+    if with_y:
+        cmp(x_out, xo, **tol(dtype))
+        assert torch.equal(x_out, outs["0"][0])
+    cmp(h, hr, **tol(dtype))
+    cmp(mean, xo.mean(1), rtol=1e-4, atol=1e-5)
+    cmp(rstd, 1 / torch.sqrt(xo.var(1, unbiased=False) + 1e-6), rtol=1e-4, atol=1e-5)
+    cmp(h, outs["0"][1], **tol(dtype))
+    cmp(mean, outs["0"][2], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_plain_ln_no_residual(dtype):
     from uwudiff_amd import ops
 

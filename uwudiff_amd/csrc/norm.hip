@@ -103,6 +103,78 @@ __global__ void __launch_bounds__(256) add_ln_mod_fwd_kernel(const T* __restrict
   }
 }
 
+// D a multiple of 128 (every DiT width): FOUR rows per wave -- a row belongs to 16 lanes, NCH = D / 128 chunks of 8 elements per
+// lane (chunk c of lane l16 = elements 128 c + 8 l16 ..: one load instruction moves 256 contiguous bytes of each of the 4 rows).
+// The kernel above keeps one 768-byte row per wave in flight (D = 384: 48 of 64 lanes busy, 1.5 KB of loads per wave and two
+// dependent whole-wave reductions per row): 604 MB in 149 us = 4.0 TB/s at M = 196608 while the backward streams at 5.6.
+// Here a wave has 6 KB of loads in flight, the statistics are four-step DPP sums inside a 16-lane row (row16_sum), and the
+// instruction stream per row shrinks 4x.
+template <typename T, int NCH>
+__global__ void __launch_bounds__(256) add_ln_mod_fwd16_kernel(const T* __restrict__ x_in, const T* __restrict__ y,
+                                                               const float* __restrict__ gate,
+                                                               const float* __restrict__ shift,
+                                                               const float* __restrict__ scale, int mod_ld,
+                                                               T* __restrict__ x_out, T* __restrict__ h,
+                                                               float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                               int M, int T_tok, float eps, int affine) {
+  constexpr int D = 128 * NCH;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane >> 4, l16 = lane & 15;
+  for (int row0 = (blockIdx.x * 4 + wave) * 4; row0 < M; row0 += gridDim.x * 16) {
+    const int row = row0 + sub;
+    const bool ok = row < M;
+    const int rc = ok ? row : M - 1;  // (every lane takes part in the DPP sums: out-of-range rows recompute the last one)
+    const int b = rc / T_tok;
+    const int64_t off = (int64_t)rc * D + 8 * l16;
+    const float* gb = gate + (int64_t)b * mod_ld + 8 * l16;
+    f32x8 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int cidx = 0; cidx < NCH; ++cidx) {
+      f32x8 xv = load8_nt(x_in + off + 128 * cidx);
+      if (y) {
+        const f32x8 yv = load8_nt(y + off + 128 * cidx), gv = load8(gb + 128 * cidx);
+        xv = xv + gv * yv;
+        if constexpr (sizeof(T) == 2) {  // keep the stored residual stream and the normalised value consistent
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xv[e] = (float)(bf16_t)xv[e];
+        }
+        if (ok) store8_nt(x_out + off + 128 * cidx, xv);
+      }
+      v[cidx] = xv;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += xv[e];
+    }
+    const float mean = row16_sum(s) * (1.f / (float)D);
+    float q = 0.f;
+#pragma unroll
+    for (int cidx = 0; cidx < NCH; ++cidx)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float c = v[cidx][e] - mean;
+        q += c * c;
+      }
+    const float var = row16_sum(q) * (1.f / (float)D);
+    const float rstd = 1.f / sqrtf(var + eps);
+    if (l16 == 0 && ok) {
+      mean_o[row] = mean;
+      rstd_o[row] = rstd;
+    }
+#pragma unroll
+    for (int cidx = 0; cidx < NCH; ++cidx) {
+      f32x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (v[cidx][e] - mean) * rstd;
+      if (scale) {
+        const f32x8 sc = load8(scale + (int64_t)b * mod_ld + 8 * l16 + 128 * cidx), sh = load8(shift + (int64_t)b * mod_ld + 8 * l16 + 128 * cidx);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = o[e] * (affine ? sc[e] : 1.f + sc[e]) + sh[e];
+      }
+      if (ok) store8(h + off + 128 * cidx, o);
+    }
+  }
+}
+
 // One workgroup = ROWS consecutive rows of ONE sample (T_tok % ROWS == 0); the 4 waves split the rows, keep the
 // per-column partial sums for dshift/dscale/dgate in registers, fold them through LDS and issue one fp32 atomic
 // per column per workgroup.
@@ -317,6 +389,31 @@ extern "C" int uwu_add_ln_modulate_fwd(const void* x_in, const void* y, const fl
   hipStream_t st = (hipStream_t)stream;
   UWU_CHECK_ARG(dtype == UWU_F32 || dtype == UWU_BF16, "add_ln_modulate_fwd: bad dtype");
   UwuProfScope prof(stream);
+  static UwuEnv r16("UWU_LN_ROW16");  // "0": the one-row-per-wave kernel at every width (A/B comparisons)
+  const bool al16 = (((uintptr_t)x_in | (uintptr_t)h | (uintptr_t)y | (uintptr_t)x_out) & 15) == 0 && (mod_ld % 4 == 0);
+  if (!r16.get().is('0') && D % 128 == 0 && D <= 1536 && al16 && M >= 4096) {
+    int g16 = (M + 15) / 16;
+    if (g16 > 4096) g16 = 4096;
+#define F16_CASE(NCH)                                                                                                          \
+  case NCH:                                                                                                                    \
+    if (dtype == UWU_F32)                                                                                                      \
+      hipLaunchKernelGGL((add_ln_mod_fwd16_kernel<float, NCH>), dim3(g16), dim3(256), 0, st, (const float*)x_in, (const float*)y, \
+                         gate, shift, scale, mod_ld, (float*)x_out, (float*)h, mean, rstd, M, T, eps, affine);                   \
+    else                                                                                                                       \
+      hipLaunchKernelGGL((add_ln_mod_fwd16_kernel<bf16_t, NCH>), dim3(g16), dim3(256), 0, st, (const bf16_t*)x_in,            \
+                         (const bf16_t*)y, gate, shift, scale, mod_ld, (bf16_t*)x_out, (bf16_t*)h, mean, rstd, M, T, eps,       \
+                         affine);                                                                                               \
+    break;
+    switch (D / 128) {
+      F16_CASE(1) F16_CASE(2) F16_CASE(3) F16_CASE(4) F16_CASE(5) F16_CASE(6) F16_CASE(7) F16_CASE(8) F16_CASE(9) F16_CASE(10)
+      F16_CASE(11) F16_CASE(12)
+    }
+#undef F16_CASE
+    const double e = dtype == UWU_BF16 ? 2.0 : 4.0, md = (double)M * D;
+    prof.done(UWU_PROF_LN_FWD, dtype == UWU_BF16 ? 0 : 1, 8.0 * md, md * e * (2 + (y ? 1 : 0) + (x_out && x_out != x_in ? 1 : 0)));
+    UWU_LAUNCH_CHECK("add_ln_modulate_fwd");
+    return UWU_OK;
+  }
 #define FWD_CASE(NIT)                                                                                              \
   case NIT:                                                                                                        \
     if (dtype == UWU_F32)                                                                                          \
