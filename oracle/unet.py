@@ -16,6 +16,10 @@ Restated semantics:
   BasicTransformer LN -> self-attn(no qkv bias) ; LN -> cross-attn(K/V from ctx) ; LN -> GEGLU(erf) FF x4 ; pre-LN residuals
                    attention = F.scaled_dot_product_attention semantics (reference rope_unet.py:122-166)
   Down/Upsample    conv3x3 stride 2 pad 1 ; nearest x2 then conv3x3
+  rope = True      RoPEUNet2DConditionModel (rope_unet.py:589-608): every Attention of a transformer block owns an AxialRoPE
+                   (`axial_rope.freqs_h / freqs_w`, rope.py:83-108); q is rotated, k only in self-attention (rope_unet.py:122-147),
+                   positions = make_axial_pos(height, width) of the feature map (rope_unet.py:476-480, rope.py:10-53)
+  init_weight_zero HDUNet2DConditionModel (rope_unet.py:562-580): exact zeros on the residual-branch output layers
 """
 import math
 
@@ -67,23 +71,65 @@ class ResnetBlock2D(nn.Module):
         return (x if self.conv_shortcut is None else self.conv_shortcut(x)) + h
 
 
+def make_axial_pos(h, w):
+    """reference src/duwu/modules/rope.py:10-53 (pixel_aspect_ratio 1, align_corners False): cell centres inside the
+    [-1, 1] bounding box of the longer side, [h * w, 2] in (y, x) order."""
+    ar = w / h
+    y_min, y_max, x_min, x_max = -1.0, 1.0, -1.0, 1.0
+    if ar > 1:
+        y_min, y_max = -1 / ar, 1 / ar
+    elif ar < 1:
+        x_min, x_max = -ar, ar
+
+    def centers(lo, hi, n):
+        e = torch.linspace(lo, hi, n + 1)
+        return (e[:-1] + e[1:]) / 2
+
+    g = torch.stack(torch.meshgrid(centers(y_min, y_max, h), centers(x_min, x_max, w), indexing="ij"), dim=-1)
+    return g.view(h * w, 2)
+
+
+def axial_rope(x, pos, log_fh, log_fw):
+    """reference rope.py:56-71, 95-108 as written (rotate_half negates the EVEN element of each pair): x [B, T, H, d],
+    pos [T, 2], log-frequencies [H, d / 4] per axis."""
+    th = torch.cat((pos[:, None, None, 0] * log_fh.exp(), pos[:, None, None, 1] * log_fw.exp()), dim=-1).repeat_interleave(2, -1)
+    rh = torch.stack((-x[..., 0::2], x[..., 1::2]), dim=-1).flatten(-2, -1)
+    return x * th.cos() + rh * th.sin()
+
+
+class _AxialRoPE(nn.Module):
+    def __init__(self, dim, heads):
+        super().__init__()
+        lf = torch.linspace(math.log(math.pi), math.log(10.0 * math.pi / 2), dim // 4).expand(heads, dim // 4)  # rope.py:74-92
+        self.freqs_h = nn.Parameter(lf.clone())
+        self.freqs_w = nn.Parameter(lf.clone())
+
+
 class Attention(nn.Module):
-    def __init__(self, dim, heads, ctx_dim=None):
+    def __init__(self, dim, heads, ctx_dim=None, rope=False):
         super().__init__()
         self.heads = heads
         self.to_q = nn.Linear(dim, dim, bias=False)
         self.to_k = nn.Linear(ctx_dim or dim, dim, bias=False)
         self.to_v = nn.Linear(ctx_dim or dim, dim, bias=False)
         self.to_out = nn.ModuleList([nn.Linear(dim, dim)])
+        if rope:
+            self.axial_rope = _AxialRoPE(dim // heads, heads)
 
-    def forward(self, x, ctx=None):
+    def forward(self, x, ctx=None, pos=None):
         B, T, D = x.shape
         bias = None
         if isinstance(ctx, tuple):  # (encoder states, additive key bias [B,1,1,S]) -- rope_unet.py:106-114, 440-453
             ctx, bias = ctx
+        self_attn = ctx is None
         ctx = x if ctx is None else ctx
         q, k, v = self.to_q(x), self.to_k(ctx), self.to_v(ctx)
-        q, k, v = [z.view(B, -1, self.heads, D // self.heads).transpose(1, 2) for z in (q, k, v)]
+        q, k, v = [z.view(B, -1, self.heads, D // self.heads) for z in (q, k, v)]
+        if pos is not None:  # rope_unet.py:143-147: q always, k only when it comes from the same tokens
+            q = axial_rope(q, pos, self.axial_rope.freqs_h, self.axial_rope.freqs_w)
+            if self_attn:
+                k = axial_rope(k, pos, self.axial_rope.freqs_h, self.axial_rope.freqs_w)
+        q, k, v = [z.transpose(1, 2) for z in (q, k, v)]
         o = F.scaled_dot_product_attention(q, k, v, attn_mask=bias).transpose(1, 2).reshape(B, T, D)
         return self.to_out[0](o)
 
@@ -108,35 +154,37 @@ class FeedForward(nn.Module):
 
 
 class BasicTransformerBlock(nn.Module):
-    def __init__(self, dim, heads, ctx_dim):
+    def __init__(self, dim, heads, ctx_dim, rope=False):
         super().__init__()
         self.norm1 = nn.LayerNorm(dim, eps=1e-5)
-        self.attn1 = Attention(dim, heads)
+        self.attn1 = Attention(dim, heads, rope=rope)
         self.norm2 = nn.LayerNorm(dim, eps=1e-5)
-        self.attn2 = Attention(dim, heads, ctx_dim)
+        self.attn2 = Attention(dim, heads, ctx_dim, rope=rope)
         self.norm3 = nn.LayerNorm(dim, eps=1e-5)
         self.ff = FeedForward(dim)
 
-    def forward(self, x, ctx):
-        x = x + self.attn1(self.norm1(x))
-        x = x + self.attn2(self.norm2(x), ctx)
+    def forward(self, x, ctx, pos=None):
+        x = x + self.attn1(self.norm1(x), pos=pos)
+        x = x + self.attn2(self.norm2(x), ctx, pos=pos)
         return x + self.ff(self.norm3(x))
 
 
 class Transformer2DModel(nn.Module):
-    def __init__(self, dim, heads, depth, ctx_dim, groups):
+    def __init__(self, dim, heads, depth, ctx_dim, groups, rope=False):
         super().__init__()
+        self.rope = rope
         self.norm = nn.GroupNorm(groups, dim, eps=1e-6)
         self.proj_in = nn.Linear(dim, dim)
-        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(dim, heads, ctx_dim) for _ in range(depth)])
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(dim, heads, ctx_dim, rope) for _ in range(depth)])
         self.proj_out = nn.Linear(dim, dim)
 
     def forward(self, x, ctx):
         B, C, H, W = x.shape
         h = self.norm(x).permute(0, 2, 3, 1).reshape(B, H * W, C)
         h = self.proj_in(h)
+        pos = make_axial_pos(H, W) if self.rope else None
         for blk in self.transformer_blocks:
-            h = blk(h, ctx)
+            h = blk(h, ctx, pos)
         h = self.proj_out(h).reshape(B, H, W, C).permute(0, 3, 1, 2)
         return h + x
 
@@ -227,7 +275,7 @@ class UNetOracle(nn.Module):
                  up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"),
                  transformer_layers_per_block=(1, 2, 10), attention_head_dim=(5, 10, 20), cross_attention_dim=2048,
                  addition_embed_type="text_time", addition_time_embed_dim=256,
-                 projection_class_embeddings_input_dim=2816, norm_num_groups=32, **_):
+                 projection_class_embeddings_input_dim=2816, norm_num_groups=32, rope=False, **_):
         super().__init__()
         boc = list(block_out_channels)
         G = norm_num_groups
@@ -241,7 +289,7 @@ class UNetOracle(nn.Module):
             self.add_embedding = TimestepEmbedding(projection_class_embeddings_input_dim, temb)
 
         def attn_cfg(i):
-            return dict(heads=attention_head_dim[i], depth=transformer_layers_per_block[i], ctx_dim=cross_attention_dim)
+            return dict(heads=attention_head_dim[i], depth=transformer_layers_per_block[i], ctx_dim=cross_attention_dim, rope=rope)
 
         self.down_blocks = nn.ModuleList()
         ch = boc[0]
@@ -258,7 +306,7 @@ class UNetOracle(nn.Module):
         for i, t in enumerate(up_block_types):
             prev, ch = ch, rev[i]
             cin = rev[min(i + 1, len(boc) - 1)]
-            a = dict(heads=rh[i], depth=rd[i], ctx_dim=cross_attention_dim) if t.startswith("CrossAttn") else None
+            a = dict(heads=rh[i], depth=rd[i], ctx_dim=cross_attention_dim, rope=rope) if t.startswith("CrossAttn") else None
             self.up_blocks.append(UpBlock(cin, ch, prev, temb, layers_per_block + 1, G, a, add_up=i < len(boc) - 1))
         self.conv_norm_out = nn.GroupNorm(G, boc[0], eps=1e-5)
         self.conv_out = nn.Conv2d(boc[0], out_channels, 3, padding=1)
@@ -274,6 +322,20 @@ class UNetOracle(nn.Module):
             if isinstance(m, ResnetBlock2D):
                 nn.init.normal_(m.conv2.weight, 0.0, 1e-5)
         nn.init.normal_(self.conv_out.weight, 0.0, 1e-5)
+
+    @torch.no_grad()
+    def init_weight_zero(self):
+        """reference rope_unet.py:562-580 (HDUNet2DConditionModel): exact zeros instead of N(0, 1e-5), biases included."""
+        for m in self.modules():
+            if isinstance(m, BasicTransformerBlock):
+                m.attn1.to_out[0].weight.zero_()
+                m.attn2.to_out[0].weight.zero_()
+                m.ff.net[2].weight.zero_()
+                m.ff.net[2].bias.zero_()
+            if isinstance(m, ResnetBlock2D):
+                m.conv2.weight.zero_()
+                m.conv2.bias.zero_()
+        self.conv_out.weight.zero_()
 
     def forward(self, sample, timestep, encoder_hidden_states=None, encoder_attention_mask=None,
                 added_cond_kwargs=None, cross_attention_kwargs=None, **kw):

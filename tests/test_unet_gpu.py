@@ -21,7 +21,7 @@ def rel(a, b):
     return ((a - b).norm() / (b.norm() + 1e-30)).item(), ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
 
 
-def run_pair(cfg, dtype, B=2, S=16, Tk=7, seed=0, mask=None):
+def run_pair(cfg, dtype, B=2, S=16, Tk=7, seed=0, mask=None, W=None):
     from oracle.unet import UNetOracle
     from uwudiff_amd.unet import UNet2DConditionModel
 
@@ -38,12 +38,13 @@ def run_pair(cfg, dtype, B=2, S=16, Tk=7, seed=0, mask=None):
     model = UNet2DConditionModel(cfg, compute_dtype=dtype).cuda()
     model.load_state_dict(ora.state_dict())
     g = torch.Generator().manual_seed(seed + 1)
-    x = torch.randn(B, cfg["in_channels"], S, S, generator=g)
+    W = W or S
+    x = torch.randn(B, cfg["in_channels"], S, W, generator=g)
     t = torch.randint(0, 1000, (B,), generator=g)
     ctx = torch.randn(B, Tk, cfg["cross_attention_dim"], generator=g)
     pooled = torch.randn(B, 16, generator=g)
     ids = torch.tensor([[1024.0, 1024, 0, 0, 1024, 1024]] * B)
-    dout = torch.randn(B, cfg["out_channels"], S, S, generator=g) / (S * S)
+    dout = torch.randn(B, cfg["out_channels"], S, W, generator=g) / (S * W)
     yo = ora(x, t, encoder_hidden_states=ctx, encoder_attention_mask=mask,
              added_cond_kwargs={"text_embeds": pooled, "time_ids": ids})[0]
     yo.backward(dout)
@@ -153,3 +154,48 @@ def test_unet_gradient_checkpointing_same_gradients_less_memory():
     err = ((g1 - g0).norm() / g0.norm()).item()
     assert err <= max(3 * noise_g, 5e-3), (err, noise_g)
     assert held1 < 0.25 * held0, (held0, held1)
+
+
+@pytest.mark.parametrize("cfg,W", [(dict(TINY, rope=True), None), (dict(PIX3, rope=True), 24)], ids=["tiny_latent", "pixel3_16x24"])
+def test_rope_unet_fp32_matches_oracle(cfg, W):
+    """RoPEUNet2DConditionModel (reference rope_unet.py:589-608): axial RoPE in every attention of every transformer block
+    (q always, k in self-attention only; positions = make_axial_pos of the feature map, also non-square), learnable
+    per-head log-frequencies with gradients -- forward and every gradient against the oracle restatement."""
+    y, yo, grads, model, ora = run_pair(cfg, "fp32", W=W)
+    l2, mx = rel(y, yo)
+    assert l2 < 1e-3 and mx < 1e-3, (l2, mx)
+    assert any("axial_rope" in n for n in grads)
+    for name, (g, go) in grads.items():
+        l2, mx = rel(g, go)
+        assert l2 < 2e-3, (name, l2, mx)
+    y0, *_ = run_pair({k: v for k, v in cfg.items() if k != "rope"}, "fp32", W=W)
+    assert rel(y, y0)[0] > 1e-2  # the rotation matters on this input
+
+
+def test_rope_unet_bf16_close_to_oracle():
+    y, yo, grads, _, _ = run_pair(dict(TINY, rope=True), "bf16", B=3)
+    l2, _ = rel(y, yo)
+    assert l2 < 4e-2, l2
+    bad = {n: rel(g, go)[0] for n, (g, go) in grads.items() if rel(g, go)[0] > 0.12}
+    assert not bad, bad
+
+
+def test_hd_unet_zero_init_is_exact_and_an_identity_free_start():
+    """HDUNet2DConditionModel (rope_unet.py:562-580): residual-branch outputs start at EXACTLY zero, so the freshly built
+    network outputs conv_out's bias = 0 everywhere, and only conv_out.weight receives a gradient."""
+    from duwu.modules.rope_unet import HDUNet2DConditionModel, RoPEUNet2DConditionModel
+
+    torch.manual_seed(0)
+    for cls in (HDUNet2DConditionModel, RoPEUNet2DConditionModel):
+        m = cls.from_config(dict(TINY), compute_dtype="fp32").cuda()
+        for n in m.P.registry:
+            if n.endswith((".conv2.weight", "attn1.to_out.0.weight", "attn2.to_out.0.weight", "ff.net.2.weight")) or n == "conv_out.weight":
+                assert float(m.P.w32(n).abs().max()) == 0.0, n
+        assert m.cfg_dict["rope"] == (cls is RoPEUNet2DConditionModel)
+        x = torch.randn(2, 4, 16, 16, device="cuda")
+        y = m(x, torch.tensor([3, 500], device="cuda"), encoder_hidden_states=torch.randn(2, 7, 32, device="cuda"),
+              added_cond_kwargs={"text_embeds": torch.randn(2, 16, device="cuda"), "time_ids": torch.zeros(2, 6, device="cuda")})[0]
+        assert float(y.detach().abs().max()) == 0.0
+        (y * torch.randn_like(y)).sum().backward()
+        nz = [n for n in m.P.registry if float(m.grad_tensor(n).abs().max()) > 0]
+        assert nz and all(n.startswith("conv_out") for n in nz), nz

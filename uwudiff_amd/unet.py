@@ -324,6 +324,21 @@ class _PackedAttentionFn(torch.autograd.Function):
         return dq, da, None, None, None, None, None, None
 
 
+class _FlatParamFn(torch.autograd.Function):
+    """a named fp32 tensor of the flat parameter buffer as an autograd leaf-like input of an op written for ordinary
+    tensors (the axial-RoPE function): its gradient is ADDED into the same slice of ``flat.grad``"""
+
+    @staticmethod
+    def forward(ctx, anchor, P, name):
+        ctx.P, ctx.name = P, name
+        return P.w32(name).clone()
+
+    @staticmethod
+    def backward(ctx, d):
+        ctx.P.g(ctx.name).add_(d.float().view_as(ctx.P.g(ctx.name)))
+        return None, None, None
+
+
 class _GegluFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, hg):
@@ -431,6 +446,10 @@ class UNet2DConditionModel(nn.Module):
         cfg = dict(SDXL_UNET_CONFIG)
         cfg.update(config or {})
         cfg.update(kw)
+        # rope: RoPEUNet2DConditionModel (reference rope_unet.py:589-608) -- an AxialRoPE per attention of every transformer block,
+        # q rotated, k only in self-attention; zero_init: HDUNet2DConditionModel's exact-zero residual-branch outputs (:562-580)
+        cfg.setdefault("rope", False)
+        cfg.setdefault("zero_init", False)
         self.cfg_dict = cfg
         c = type("cfg", (), cfg)()
         c.compute_dtype = compute_dtype
@@ -467,7 +486,10 @@ class UNet2DConditionModel(nn.Module):
             if cin != cout:
                 lin(name + ".conv_shortcut", cin, cout)
 
-        def t2d(name, dim, depth):
+        self._t2d_heads = {}
+
+        def t2d(name, dim, depth, nheads):
+            self._t2d_heads[name] = nheads
             norm(name + ".norm", dim)
             lin(name + ".proj_in", dim, dim)
             ctx_dim = cfg["cross_attention_dim"]
@@ -479,6 +501,10 @@ class UNet2DConditionModel(nn.Module):
                     lin(f"{b}.{a}.to_k", kd, dim, bias=False)
                     lin(f"{b}.{a}.to_v", kd, dim, bias=False)
                     lin(f"{b}.{a}.to_out.0", dim, dim)
+                    if cfg["rope"]:  # AxialRoPE(head_dim, heads): log-frequencies [heads, head_dim / 4] per axis (rope.py:83-92)
+                        nh = self._t2d_heads[name]
+                        P.add(f"{b}.{a}.axial_rope.freqs_h", (nh, dim // nh // 4))
+                        P.add(f"{b}.{a}.axial_rope.freqs_w", (nh, dim // nh // 4))
                     if a == "attn1":
                         norm(b + ".norm2", dim)
                 norm(b + ".norm3", dim)
@@ -504,7 +530,7 @@ class UNet2DConditionModel(nn.Module):
                 blk["res"].append((n, cin if j == 0 else ch, ch))
                 if attn:
                     a = f"down_blocks.{i}.attentions.{j}"
-                    t2d(a, ch, depths[i])
+                    t2d(a, ch, depths[i], heads[i])
                     blk["attn"].append((a, depths[i]))
             if i < len(boc) - 1:
                 d = f"down_blocks.{i}.downsamplers.0.conv"
@@ -513,7 +539,7 @@ class UNet2DConditionModel(nn.Module):
             self.plan_down.append(blk)
         mid = boc[-1]
         resnet("mid_block.resnets.0", mid, mid)
-        t2d("mid_block.attentions.0", mid, depths[-1])
+        t2d("mid_block.attentions.0", mid, depths[-1], heads[-1])
         resnet("mid_block.resnets.1", mid, mid)
         self.mid_heads, self.mid_depth = heads[-1], depths[-1]
         rev, rh, rd = boc[::-1], heads[::-1], depths[::-1]
@@ -532,7 +558,7 @@ class UNet2DConditionModel(nn.Module):
                 blk["res"].append((n, rin, ch))
                 if attn:
                     a = f"up_blocks.{i}.attentions.{j}"
-                    t2d(a, ch, rd[i])
+                    t2d(a, ch, rd[i], rh[i])
                     blk["attn"].append((a, rd[i]))
             if i < len(boc) - 1:
                 u = f"up_blocks.{i}.upsamplers.0.conv"
@@ -553,9 +579,12 @@ class UNet2DConditionModel(nn.Module):
     def reset_parameters(self):
         """torch default inits per layer type + reference unet_patch.py:34-45 (N(0,1e-5) on residual out layers)."""
         g = torch.Generator().manual_seed(torch.initial_seed() % (2 ** 31))
+        zero = self.cfg_dict["zero_init"]
         for name, (off, shape) in self.P.registry.items():
             v = self.P.w32(name)
-            if name.endswith(".bias"):
+            if ".axial_rope." in name:  # rope.py:74-81 freqs_pixel_log(max_freq = 10): linspace(log pi, log 5 pi) per head
+                v.copy_(torch.linspace(math.log(math.pi), math.log(10.0 * math.pi / 2), shape[-1]).expand(shape))
+            elif name.endswith(".bias"):
                 v.zero_()
             elif len(shape) == 1:
                 v.fill_(1.0)  # norm gains
@@ -569,6 +598,8 @@ class UNet2DConditionModel(nn.Module):
                 if name.endswith((".conv2.weight", "attn1.to_out.0.weight", "attn2.to_out.0.weight", "ff.net.2.weight",
                                   "conv_out.weight")) and "samplers" not in name:
                     v.copy_(torch.randn(shape, generator=g) * 1e-5)
+                    if zero:  # rope_unet.py:562-580: exact zeros (the biases of these layers are zero already)
+                        v.zero_()
         self._zero_padding()
         self.refresh_shadow()
 
@@ -692,8 +723,33 @@ class UNet2DConditionModel(nn.Module):
             x = self._linear(x, name + ".conv_shortcut")
         return _AddFn.apply(x, h)
 
+    def _rope_pos(self, B, hw, dev):
+        """make_axial_pos(height, width) of the feature map (rope_unet.py:476-480), one row per token row of the batch"""
+        key = (B, hw, dev)
+        if getattr(self, "_pos_key", None) != key:
+            from .rope import make_axial_pos
+
+            self._pos = make_axial_pos(hw[0], hw[1]).float().to(dev).repeat(B, 1).contiguous()
+            self._pos_key = key
+        return self._pos
+
     def _attn(self, x, ctx, name, B, T, Tk, heads, key_bias=None):
         D = x.shape[1]
+        if self.cfg_dict["rope"]:
+            # separate projections (the rotation needs q / k as tensors of their own), q rotated, k only in self-attention
+            from .rope import _RopeFn
+
+            q = self._linear(x, name + ".to_q", bias=False)
+            src = x if ctx is None else ctx
+            k = self._linear(src, name + ".to_k", bias=False)
+            v = self._linear(src, name + ".to_v", bias=False)
+            pos = self._rope_pos(B, self._hw, x.device)
+            fh, fw = _FlatParamFn.apply(self.flat, self.P, name + ".axial_rope.freqs_h"), _FlatParamFn.apply(self.flat, self.P, name + ".axial_rope.freqs_w")
+            q = _RopeFn.apply(q, pos, fh, fw, heads, D // heads)
+            if ctx is None:
+                k = _RopeFn.apply(k, pos, fh, fw, heads, D // heads)
+            o = _AttentionFn.apply(q, k, v, B, T, Tk, heads, D // heads, key_bias)
+            return self._linear(o, name + ".to_out.0")
         # q|k|v (self-attention) and k|v (cross-attention) weights sit back to back in the flat buffer: one stacked
         # projection instead of three (two), forward and backward
         if ctx is None:
@@ -717,6 +773,7 @@ class UNet2DConditionModel(nn.Module):
         return self._linear(o, name + ".to_out.0")
 
     def _t2d(self, x, ctx, name, depth, heads, B, HW, C, Tk):
+        self._hw = self._hw_of[HW]
         h = _GroupNormFn.apply(x, self.P, name + ".norm", B, HW, C, self.G, 1e-6, False)
         h = self._linear(h, name + ".proj_in")
         ones = self._ones(C, h.device)
@@ -789,6 +846,11 @@ class UNet2DConditionModel(nn.Module):
         x = self._conv(x, "conv_in", B, H, W, self.cin_pad)
         skips = [(x, boc[0])]
         h, w = H, W
+        self._hw_of = {}  # token count -> (height, width) of the feature maps of this call (positions of the RoPE variant)
+        hh, ww = H, W
+        for _ in range(len(boc)):
+            self._hw_of[hh * ww] = (hh, ww)
+            hh, ww = (hh + 1) // 2, (ww + 1) // 2
         for blk in self.plan_down:
             for j, (n, cin, cout) in enumerate(blk["res"]):
                 x = self._seg(self._resnet, x, emb_act, n, cin, cout, B, h, w)
@@ -825,7 +887,8 @@ class UNet2DConditionModel(nn.Module):
         kw.pop("subfolder", None)
         if isinstance(config, str):
             presets = {"sdxl": SDXL_UNET_CONFIG, "stabilityai/stable-diffusion-xl-base-1.0": SDXL_UNET_CONFIG,
-                       "tiny-unet": TINY_UNET_CONFIG}
+                       "tiny-unet": TINY_UNET_CONFIG, "sdxl-rope": dict(SDXL_UNET_CONFIG, rope=True, zero_init=True),
+                       "sdxl-hd": dict(SDXL_UNET_CONFIG, zero_init=True)}
             if config not in presets:
                 raise ValueError(f"unknown UNet config {config!r}; known: {sorted(presets)}")
             config = presets[config]
