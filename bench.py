@@ -128,7 +128,8 @@ def self_launch(n):
 FAMILIES = [(0, "gemm_fwd (qkv / proj / fc2 forward)", "mfma"), (1, "gemm_dgrad (input gradients)", "mfma"),
             (2, "gemm_wgrad (streaming weight gradients + split-K reduce)", "mfma"),
             (3, "gemm fc1 + bias + GELU", "mfma"), (4, "gemm fc2 dgrad + dGELU", "mfma"),
-            (5, "attn_fwd_mfma", "mfma"), (6, "attn_bwd_mfma", "mfma"),
+            (5, "attention forward (attn_fwd_p256 at T = 256 / head dim 64, else attn_fwd_mfma)", "mfma"),
+            (6, "attention backward (attn_bwd_p256 at T = 256 / head dim 64, else attn_bwd_mfma [+ attn_bwd_dq_mfma])", "mfma"),
             (7, "add_ln_mod_fwd", "hbm"), (8, "add_ln_mod_bwd", "hbm")]
 PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md "Chip-level parameters" (spec; 6.3 TB/s is what a copy reaches)
 

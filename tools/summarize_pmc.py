@@ -46,3 +46,37 @@ out = {
 }
 print(json.dumps(out, indent=1))
 json.dump(out, open(sys.argv[3], "w"), indent=1)
+
+
+# ---- per-kernel table (every kernel of the step, not only the GEMM family): counter-check of the algorithmic GB/s figures
+def by_kernel(dirname, counter):
+    import re
+
+    f = glob.glob(f"{dirname}/**/*counter_collection.csv", recursive=True)[0]
+    acc = {}
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        m = re.search(r"(\w+_kernel|attn_\w+|\w+kernel\w*)(<[^>]*>)?", r["Kernel_Name"])
+        k = (m.group(1) + (m.group(2) or "")) if m else r["Kernel_Name"][:60]
+        a = acc.setdefault(k[:72], [0.0, 0])
+        a[0] += float(r["Counter_Value"])
+        a[1] += 1
+    return acc
+
+
+fk, wk = by_kernel(sys.argv[1], "FETCH_SIZE"), by_kernel(sys.argv[2], "WRITE_SIZE")
+rows = []
+for k in sorted(set(fk) | set(wk)):
+    rd = 2.0 * fk.get(k, [0, 1])[0] / max(fk.get(k, [0, 1])[1], 1) * 1024 / 1e6
+    wr = wk.get(k, [0, 1])[0] / max(wk.get(k, [0, 1])[1], 1) * 1024 / 1e6
+    rows.append((rd + wr, k, fk.get(k, [0, 0])[1], rd, wr))
+rows.sort(reverse=True)
+table = sys.argv[3].replace(".json", "_by_kernel.txt")
+with open(table, "w") as fo:
+    fo.write("# HBM traffic per launch by kernel (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over `python bench.py`;\n"
+             "# read = 2 x FETCH_SIZE KiB (gfx950 tallies 128-B requests at 64 B), written = WRITE_SIZE KiB; MB = 1e6 bytes)\n")
+    fo.write(f"{'kernel':72s} {'launches':>8s} {'read MB':>10s} {'written MB':>11s} {'total MB':>10s}\n")
+    for tot, k, n, rd, wr in rows[:40]:
+        fo.write(f"{k:72s} {n:8d} {rd:10.1f} {wr:11.1f} {tot:10.1f}\n")
+print(open(table).read())

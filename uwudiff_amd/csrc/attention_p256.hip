@@ -643,9 +643,14 @@ int uwu_attn_p256_bwd(const void* q, const void* k, const void* v, const void* o
   return UWU_OK;
 }
 
-bool uwu_attn_p256_fwd_ok(int T, int Tk, int d, int ldq, int ldk, int ldv, int ldo) {
-  static UwuEnv on("UWU_ATTN_P256F");  // "0": the kernel of attention_mfma.hip (A/B comparisons)
-  return !on.get().is('0') && T == 256 && Tk == 256 && d == 64 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0;
+bool uwu_attn_p256_fwd_ok(int nheads, int T, int Tk, int d, int ldq, int ldk, int ldv, int ldo) {
+  static UwuEnv on("UWU_ATTN_P256F");  // "0": the kernel of attention_mfma.hip (A/B comparisons); "1": at every head count
+  if (on.get().is('0')) return false;
+  // One workgroup per CU walking nheads / 256 heads: with few heads per workgroup the uneven shares (384 heads: 19.6 us
+  // against 16.0 for the two-workgroups-per-head kernel) and the lack of a second workgroup per CU cost more than the
+  // streaming gains (768 heads: 28.6 vs 27.0 us; 4608: 155 vs 160).  The backward wins at every size (96 heads: 19 vs 23 us).
+  if (!on.is('1') && nheads < 1024) return false;
+  return T == 256 && Tk == 256 && d == 64 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0;
 }
 
 int uwu_attn_p256_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int ldq, int ldk, int ldv,
