@@ -10,6 +10,7 @@
 #include <math.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/uwu_hip.h"
 
@@ -25,6 +26,7 @@ struct Layout {
   int64_t M, D, D3, D4, Kp, Ko;
   // fp32 conditioning path
   size_t feat, t_pre, t_h, temb, yemb, c, sc, mod;
+  size_t sc16, dmod16;  // bf16 mode, B >= 64: bf16 copies of silu(c) and of d(mod) -- operands of the adaLN Linear on the bf16 MFMA path
   // token path
   size_t tok, xe;
   size_t layer0, layer_stride;
@@ -68,6 +70,8 @@ Layout make_layout(const uwu_dit_desc& d) {
   L.c = take((size_t)d.B * d.D * f4);
   L.sc = take((size_t)d.B * d.D * f4);
   L.mod = take((size_t)d.B * d.mod_total * f4);
+  L.sc16 = take((size_t)d.B * d.D * 2);
+  L.dmod16 = take((size_t)d.B * d.mod_total * 2);
   L.tok = take(L.M * L.Kp * L.es);
   L.xe = take(L.M * L.D * L.es);
   // per-layer block
@@ -207,6 +211,19 @@ int lin_dgrad(const void* dY, const void* W, void* dX, const void* aux, int M, i
               float* colsum = nullptr) {
   return uwu_gemm(dY, W, dX, colsum, nullptr, aux, M, K, N, N, K, K, K, 0, 1, dt, dt,
                   aux ? UWU_EPI_DGELU : UWU_EPI_NONE, 1, st);
+}
+// The batched adaLN Linear (D -> L*6*D + 2*D outputs per sample) on the bf16 MFMA path: bf16 operands (the bf16 shadow of the
+// weight; silu(c) and d(mod) cast once), fp32 accumulate and fp32 outputs.  In the exact-fp32 MFMA mode (1/16 of the bf16 rate) its
+// three GEMMs were 0.85 ms of the 45 ms step at B = 768 (16.5 GFLOP each).  The reference runs this Linear under bf16 autocast
+// like every other one (Lightning precision "bf16-mixed", configs/demo_training_latent.yaml); the fp32 parity mode and small
+// batches (where the matrix-vector kernels take the conditioning Linears) are unchanged.  UWU_DIT_MOD_BF16=0: off (A/B).
+static bool mod_bf16(const uwu_dit_desc& d) {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("UWU_DIT_MOD_BF16");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v == 1 && d.dtype == UWU_BF16 && d.B >= 64 && d.mod_total % 8 == 0;
 }
 // dX[M,K] = dY[M,N] . W[N,K] for a LONG reduction N and few rows M (the batched adaLN linear: N = L*6*D+2*D):
 // split the reduction over workgroups and accumulate with fp32 atomics into a zeroed dX.
@@ -507,7 +524,12 @@ extern "C" int uwu_dit_forward(const uwu_dit_desc* dp, const float* noisy, const
     cptr = P.at(L.c);
   }
   RUN(uwu_silu_fwd(cptr, P.at(L.sc), (int64_t)B * D, UWU_F32, st));
-  RUN(lin_fwd32(P.at<float>(L.sc), w32 + d.off_mod_w, w32 + d.off_mod_b, P.at<float>(L.mod), nullptr, B, ML, D, UWU_EPI_BIAS, st));
+  if (mod_bf16(d)) {
+    RUN(uwu_cast_f32_to_bf16(P.at<float>(L.sc), P.at(L.sc16), (int64_t)B * D, st));
+    RUN(lin_fwd(P.at(L.sc16), wb + d.off_mod_w * es, w32 + d.off_mod_b, P.at(L.mod), nullptr, B, ML, D, UWU_BF16, UWU_F32, UWU_EPI_BIAS, st));
+  } else {
+    RUN(lin_fwd32(P.at<float>(L.sc), w32 + d.off_mod_w, w32 + d.off_mod_b, P.at<float>(L.mod), nullptr, B, ML, D, UWU_EPI_BIAS, st));
+  }
   const float* mod = P.at<float>(L.mod);
 
   // ---- fp8 mode: this step's weights as fp8 (W for the forward, W^T for the input gradients), scaled per tensor
@@ -707,8 +729,26 @@ extern "C" int uwu_dit_backward(const uwu_dit_desc* dp, const float* dout, void*
   RUN(uwu_colsum(P.at(L.dx), dt, M, D, D, g + d.off_patch_b, 1, st));
 
   // ---- conditioning path (fp32)
-  RUN(lin_wgrad32(dmod, P.at<float>(L.sc), g + d.off_mod_w, g + d.off_mod_b, B, ML, D, st));
-  RUN(lin_dgrad_splitk(dmod, w32 + d.off_mod_w, P.at<float>(L.dsc), B, ML, D, st));  // (matrix-vector form: 99 us vs 40)
+  if (mod_bf16(d)) {
+    // dW += d(mod)^T . silu(c), db += colsum(d(mod)) (fp32), d(silu c) = d(mod) . W: bf16 operands, fp32 accumulation / outputs
+    RUN(uwu_cast_f32_to_bf16(dmod, P.at(L.dmod16), (int64_t)B * ML, st));
+    RUN(lin_wgrad(P.at(L.dmod16), P.at(L.sc16), g + d.off_mod_w, B, ML, D, UWU_BF16, st));
+    RUN(uwu_colsum(dmod, UWU_F32, B, ML, ML, g + d.off_mod_b, 1, st));
+    if (hipMemsetAsync(P.at(L.dsc), 0, (size_t)B * D * sizeof(float), (hipStream_t)st) != hipSuccess) {
+      uwu_set_error("dit_backward: memset failed");
+      return UWU_ELAUNCH;
+    }
+    {
+      const int tiles = ((B + 127) / 128) * ((D + 127) / 128), ktiles = (ML + 63) / 64;
+      int split = (512 + tiles - 1) / tiles;
+      if (split > ktiles) split = ktiles;
+      RUN(uwu_gemm(P.at(L.dmod16), wb + d.off_mod_w * es, P.at(L.dsc), nullptr, nullptr, nullptr, B, D, ML, ML, D, D, 0, 0, 1, UWU_BF16,
+                   UWU_F32, UWU_EPI_ACCUM, split, st));
+    }
+  } else {
+    RUN(lin_wgrad32(dmod, P.at<float>(L.sc), g + d.off_mod_w, g + d.off_mod_b, B, ML, D, st));
+    RUN(lin_dgrad_splitk(dmod, w32 + d.off_mod_w, P.at<float>(L.dsc), B, ML, D, st));  // (matrix-vector form: 99 us vs 40)
+  }
   const void* cptr = d.cond_dim > 0 ? P.at(L.c) : P.at(L.temb);
   RUN(uwu_silu_bwd(cptr, P.at(L.dsc), P.at(L.dc), (int64_t)B * D, UWU_F32, st));
   if (d.cond_dim > 0) {
