@@ -4,8 +4,9 @@
 // 344-349, 393-411) and attention processor (:122-166); the call contract is diffusion.py:172-176.
 //
 // Precision policy: activations and GEMM operands in `dtype` (bf16 or fp32), fp32 accumulation, fp32 LN
-// statistics / softmax / modulation.  The conditioning path (timestep MLP, pooled-text projection, the
-// batched adaLN linear: M = B rows only) always runs in fp32 from the fp32 master weights.
+// statistics / softmax / modulation.  The conditioning path (timestep MLP, pooled-text projection: M = B
+// rows only) runs in fp32 from the fp32 master weights; the batched adaLN Linear does too in fp32 mode and at
+// small batches, and takes bf16 operands with fp32 accumulation / outputs in bf16 mode at B >= 64 (mod_bf16).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stddef.h>

@@ -25,6 +25,26 @@ __device__ __forceinline__ void store8_nt(bf16_t* p, f32x8 v) {
   __builtin_nontemporal_store(*reinterpret_cast<nu32x4*>(&o), reinterpret_cast<nu32x4*>(p));
 }
 
+// the same 8 elements kept in their storage type (bf16: 4 registers instead of 8) until they are needed as fp32
+template <typename T> struct Raw8;
+template <> struct Raw8<float> { typedef f32x8 type; };
+template <> struct Raw8<bf16_t> { typedef bf16x8 type; };
+__device__ __forceinline__ f32x8 raw8_nt(const float* p) { return load8(p); }
+__device__ __forceinline__ bf16x8 raw8_nt(const bf16_t* p) {
+  typedef unsigned nu32x4 __attribute__((ext_vector_type(4)));
+  nu32x4 raw = __builtin_nontemporal_load(reinterpret_cast<const nu32x4*>(p));
+  return *reinterpret_cast<bf16x8*>(&raw);
+}
+__device__ __forceinline__ f32x8 raw8(const float* p) { return load8(p); }
+__device__ __forceinline__ bf16x8 raw8(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ f32x8 unpack8(f32x8 v) { return v; }
+__device__ __forceinline__ f32x8 unpack8(bf16x8 v) {
+  f32x8 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r[i] = (float)v[i];
+  return r;
+}
+
 constexpr int MAX_D = 4096;  // 16-byte vectors: 8 elements per lane, NIT = ceil(D/512) (template parameter)
 
 template <typename T, int MAX_IT>
@@ -199,67 +219,151 @@ __global__ void __launch_bounds__(64 * NW) add_ln_mod_bwd_kernel(
     if (row >= M) break;
     const int64_t off = (int64_t)row * D;
     const float mean = mean_i[row], rstd = rstd_i[row];
-    f32x8 xh[MAX_IT], g[MAX_IT];
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int it = 0; it < MAX_IT; ++it) {
-      const int d = it * 512 + lane * 8;
-      if (it < nit && d < D) {
-        // streaming accesses for what is read once here (x, y, dx_in) and for dx_out (next read two GEMMs later); dh was
-        // just written by the previous GEMM and dy feeds the next one (M = 196608: 189 -> 177 us)
-        f32x8 xv = load8_nt(x + off + d), dv = load8(dh + off + d);
-        f32x8 sc = scale ? load8(scale + (int64_t)b * mod_ld + d)
-                         : (affine ? f32x8{1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f} : f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float xhat = (xv[e] - mean) * rstd;
-          float gg = dv[e] * (affine ? sc[e] : 1.f + sc[e]);
-          xh[it][e] = xhat;
-          g[it][e] = gg;
-          s1 += gg;
-          s2 += gg * xhat;
-          a_sh[it][e] += dv[e];
-          a_sc[it][e] += dv[e] * xhat;
+    if constexpr (MAX_IT == 1) {  // D <= 512: everything fits in registers as fp32 (88-92 VGPRs)
+      f32x8 xh[MAX_IT], g[MAX_IT];
+      float s1 = 0.f, s2 = 0.f;
+  #pragma unroll
+      for (int it = 0; it < MAX_IT; ++it) {
+        const int d = it * 512 + lane * 8;
+        if (it < nit && d < D) {
+          // streaming accesses for what is read once here (x, y, dx_in) and for dx_out (next read two GEMMs later); dh was
+          // just written by the previous GEMM and dy feeds the next one (M = 196608: 189 -> 177 us)
+          f32x8 xv = load8_nt(x + off + d), dv = load8(dh + off + d);
+          f32x8 sc = scale ? load8(scale + (int64_t)b * mod_ld + d)
+                           : (affine ? f32x8{1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f} : f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
+  #pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float xhat = (xv[e] - mean) * rstd;
+            float gg = dv[e] * (affine ? sc[e] : 1.f + sc[e]);
+            xh[it][e] = xhat;
+            g[it][e] = gg;
+            s1 += gg;
+            s2 += gg * xhat;
+            a_sh[it][e] += dv[e];
+            a_sc[it][e] += dv[e] * xhat;
+          }
         }
       }
-    }
-    s1 = wave_sum(s1) / (float)D;
-    s2 = wave_sum(s2) / (float)D;
-#pragma unroll
-    for (int it = 0; it < MAX_IT; ++it) {
-      const int d = it * 512 + lane * 8;
-      if (it < nit && d < D) {
-        f32x8 dx;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dx[e] = rstd * (g[it][e] - s1 - xh[it][e] * s2);
-        if (dx_in) dx = dx + load8_nt(dx_in + off + d);
-        store8_nt(dx_out + off + d, dx);
-        if (y) {
-          f32x8 yv = load8_nt(y + off + d), gv = load8(gate + (int64_t)b * mod_ld + d);
-          store8(dy + off + d, gv * dx);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) a_g[it][e] += dx[e] * yv[e];
+      s1 = wave_sum(s1) / (float)D;
+      s2 = wave_sum(s2) / (float)D;
+  #pragma unroll
+      for (int it = 0; it < MAX_IT; ++it) {
+        const int d = it * 512 + lane * 8;
+        if (it < nit && d < D) {
+          f32x8 dx;
+  #pragma unroll
+          for (int e = 0; e < 8; ++e) dx[e] = rstd * (g[it][e] - s1 - xh[it][e] * s2);
+          if (dx_in) dx = dx + load8_nt(dx_in + off + d);
+          store8_nt(dx_out + off + d, dx);
+          if (y) {
+            f32x8 yv = load8_nt(y + off + d), gv = load8(gate + (int64_t)b * mod_ld + d);
+            store8(dy + off + d, gv * dx);
+  #pragma unroll
+            for (int e = 0; e < 8; ++e) a_g[it][e] += dx[e] * yv[e];
+          }
+        }
+      }
+    } else {
+      // Wide rows (MAX_IT >= 2): x and dh stay in their storage type between the two passes and the modulation vector is read
+      // again (L1 / L2) -- with fp32 copies of xhat, g and the scale the D = 1152 instantiation needed 194 registers (2 waves
+      // per SIMD: too few loads in flight for an HBM-bound kernel)
+      typename Raw8<T>::type xr[MAX_IT], dr[MAX_IT];
+      float s1 = 0.f, s2 = 0.f;
+      auto scale_of = [&](int d) {
+        return scale ? load8(scale + (int64_t)b * mod_ld + d)
+                     : (affine ? f32x8{1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f} : f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
+      };
+  #pragma unroll
+      for (int it = 0; it < MAX_IT; ++it) {
+        const int d = it * 512 + lane * 8;
+        if (it < nit && d < D) {
+          // streaming accesses for what is read once here (x, y, dx_in) and for dx_out (next read two GEMMs later); dh was
+          // just written by the previous GEMM and dy feeds the next one (M = 196608: 189 -> 177 us)
+          xr[it] = raw8_nt(x + off + d);
+          dr[it] = raw8(dh + off + d);
+          const f32x8 xv = unpack8(xr[it]), dv = unpack8(dr[it]), sc = scale_of(d);
+  #pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float xhat = (xv[e] - mean) * rstd;
+            float gg = dv[e] * (affine ? sc[e] : 1.f + sc[e]);
+            s1 += gg;
+            s2 += gg * xhat;
+            a_sh[it][e] += dv[e];
+            a_sc[it][e] += dv[e] * xhat;
+          }
+        }
+      }
+      s1 = wave_sum(s1) / (float)D;
+      s2 = wave_sum(s2) / (float)D;
+  #pragma unroll
+      for (int it = 0; it < MAX_IT; ++it) {
+        const int d = it * 512 + lane * 8;
+        if (it < nit && d < D) {
+          const f32x8 xv = unpack8(xr[it]), dv = unpack8(dr[it]), sc = scale_of(d);
+          f32x8 dx;
+  #pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float xhat = (xv[e] - mean) * rstd, gg = dv[e] * (affine ? sc[e] : 1.f + sc[e]);
+            dx[e] = rstd * (gg - s1 - xhat * s2);
+          }
+          if (dx_in) dx = dx + load8_nt(dx_in + off + d);
+          store8_nt(dx_out + off + d, dx);
+          if (y) {
+            f32x8 yv = load8_nt(y + off + d), gv = load8(gate + (int64_t)b * mod_ld + d);
+            store8(dy + off + d, gv * dx);
+  #pragma unroll
+            for (int e = 0; e < 8; ++e) a_g[it][e] += dx[e] * yv[e];
+          }
         }
       }
     }
   }
-  // fold the 4 waves' column partials
-  float* mine = red + (int64_t)wave * 3 * D;
+  // fold the waves' column partials.  D <= 1024: one LDS slab per wave, summed by the flushing threads.  Wider rows: ONE slab,
+  // the waves add to it in turn (a slab per wave = 55 KB at D = 1152: two workgroups per CU, 2 waves per SIMD, 3.4 TB/s)
+  constexpr bool ONE_SLAB = MAX_IT >= 3;
+  float* mine = red + (ONE_SLAB ? 0 : (int64_t)wave * 3 * D);
+  if constexpr (ONE_SLAB) {
+    for (int w = 0; w < NW; ++w) {
+      if (wave == w) {
 #pragma unroll
-  for (int it = 0; it < MAX_IT; ++it) {
-    const int d = it * 512 + lane * 8;
-    if (it < nit && d < D) {
-      store8(mine + d, a_sh[it]);
-      store8(mine + D + d, a_sc[it]);
-      store8(mine + 2 * D + d, a_g[it]);
+        for (int it = 0; it < MAX_IT; ++it) {
+          const int d = it * 512 + lane * 8;
+          if (it < nit && d < D) {
+            if (w == 0) {
+              store8(mine + d, a_sh[it]);
+              store8(mine + D + d, a_sc[it]);
+              store8(mine + 2 * D + d, a_g[it]);
+            } else {
+              store8(mine + d, load8(mine + d) + a_sh[it]);
+              store8(mine + D + d, load8(mine + D + d) + a_sc[it]);
+              store8(mine + 2 * D + d, load8(mine + 2 * D + d) + a_g[it]);
+            }
+          }
+        }
+      }
+      __syncthreads();
     }
+  } else {
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it) {
+      const int d = it * 512 + lane * 8;
+      if (it < nit && d < D) {
+        store8(mine + d, a_sh[it]);
+        store8(mine + D + d, a_sc[it]);
+        store8(mine + 2 * D + d, a_g[it]);
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
   const int ncol = (y ? 3 : 2) * D;
   for (int c = threadIdx.x; c < ncol; c += 64 * NW) {
     float t = 0.f;
+    if constexpr (ONE_SLAB) {
+      t = red[c];
+    } else {
 #pragma unroll
-    for (int w = 0; w < NW; ++w) t += red[w * 3 * D + c];
+      for (int w = 0; w < NW; ++w) t += red[w * 3 * D + c];
+    }
     const int which = c / D, d = c - which * D;
     float* dst = which == 0 ? dshift : (which == 1 ? dscale : dgate);
     if (dst) atomicAdd(dst + (int64_t)b * mod_ld + d, t);
@@ -391,7 +495,9 @@ extern "C" int uwu_add_ln_modulate_fwd(const void* x_in, const void* y, const fl
   UwuProfScope prof(stream);
   static UwuEnv r16("UWU_LN_ROW16");  // "0": the one-row-per-wave kernel at every width (A/B comparisons)
   const bool al16 = (((uintptr_t)x_in | (uintptr_t)h | (uintptr_t)y | (uintptr_t)x_out) & 15) == 0 && (mod_ld % 4 == 0);
-  if (!r16.get().is('0') && D % 128 == 0 && D <= 1536 && al16 && M >= 4096) {
+  // (up to D = 768: 126 registers, 4 waves per SIMD; at D = 1152 its 174 registers left 2 waves per SIMD and it ran at 3.6 TB/s
+  //  against the one-row-per-wave kernel's 4.7 -- UWU_LN_ROW16=1 forces it up to D = 1536)
+  if (!r16.get().is('0') && D % 128 == 0 && D <= (r16.get().is('1') ? 1536 : 768) && al16 && M >= 4096) {
     int g16 = (M + 15) / 16;
     if (g16 > 4096) g16 = 4096;
 #define F16_CASE(NCH)                                                                                                          \
@@ -531,7 +637,7 @@ extern "C" int uwu_add_ln_modulate_bwd(const void* dh, const void* x, const floa
     }
     if (forced > 0 && T % forced == 0) rows = forced;
   }
-  const size_t lds = (size_t)(small ? 8 : 4) * 3 * D * sizeof(float);
+  const size_t lds = (size_t)(small ? 8 : (D > 1024 ? 1 : 4)) * 3 * D * sizeof(float);  // (D > 1024: MAX_IT >= 3, one slab)
   if (small) {
     UwuProfScope prof(stream);
 #define SMALL_CASE(NIT)                                                                                                \
