@@ -192,6 +192,20 @@ int uwu_gemm_fp8(const void* A, const void* B, void* C, void* C2, const float* b
                  int K, int lda, int ldb, int ldc, int ldaux, int fmt_a, int epilogue, const float* scale_a,
                  const float* scale_b, void* scratch, size_t scratch_bytes, void* stream);
 
+/* The same GEMM whose epilogue also EMITS the fp8 operand of the next GEMMs (delayed scaling: the scale of a tensor is
+ * known before the tensor exists), so that no quantising pass reads the bf16 result again:
+ *   UWU_EPI_BIAS_GELU: C = bf16 pre-activation A.B^T + bias (required: the backward pass reads it), q8 [M,N] / q8t [N,M] =
+ *                      e4m3(gelu(pre-activation) * q_scale[0])
+ *   UWU_EPI_DGELU:     v = (A.B^T) * gelu'(aux); C must be NULL (no bf16 copy); colsum[N] += column sums of v if non-NULL;
+ *                      q8 / q8t = e5m2(v * q_scale[0])
+ * q_amax (optional) receives max |value| by atomic max (the next step's scale).  Either of q8 / q8t may be NULL.
+ * M, N multiples of 16; ldq >= N, ldqt >= M, multiples of 16.  Reference: the MLP of the transformer block,
+ * rope_unet.py:399-411 (nn.Linear -> GELU(tanh) -> nn.Linear under autocast); the fp8 path is this build's (config 5). */
+int uwu_gemm_fp8_emit(const void* A, const void* B, void* C, float* colsum, const float* bias, const void* aux, int M, int N,
+                      int K, int lda, int ldb, int ldc, int ldaux, int fmt_a, int epilogue, const float* scale_a,
+                      const float* scale_b, void* q8, int ldq, void* q8t, int ldqt, const float* q_scale, float* q_amax,
+                      void* stream);
+
 /* 3x3 convolution, padding 1, stride 1 or 2, channels-last bf16, as an implicit GEMM: the MFMA ring kernels gather
  * their activation operand pixel by pixel (per-lane LDS-DMA source addresses, a zero page for the padding) so no
  * im2col matrix exists in HBM (reference: the resblock / down / up-sample Conv2d of diffusers' UNet2DConditionModel,

@@ -138,6 +138,63 @@ def test_gemm_fp8_weight_gradient_accumulates(fmt_a):
     assert (dw.cpu() - full).norm() / full.norm() < 8e-2
 
 
+@pytest.mark.parametrize("epi,M,N,K", [("bias_gelu", 1024, 768, 1152), ("dgelu", 1024, 768, 1152), ("bias_gelu", 640, 1536, 384),
+                                       ("dgelu", 896, 512, 256)])
+def test_gemm_fp8_emit_matches_quantised_result(epi, M, N, K):
+    """The epilogue that emits the next GEMM's fp8 operand (row-major + transposed) against the two-pass form: the bf16
+    pre-activation matches the plain kernel's (to a flipped bf16 rounding), the transposed image is the exact transpose of the row-major one,
+    the bytes are the RNE quantisation of the fp32 result (the plain path rounds to bf16 first: checked within one fp8 step),
+    amax / column sums match.  M = 640 / 896: a ragged last 256-row tile."""
+    from uwudiff_amd import lib as L
+    from uwudiff_amd import ops
+
+    torch.manual_seed(11)
+    fmt_a = 1 if epi == "dgelu" else 0
+    a, b = torch.randn(M, K) * (1e-2 if fmt_a else 1.0), torch.randn(N, K) * 0.05
+    bias = torch.randn(N)
+    aux = torch.randn(M, N).bfloat16()
+    sa = torch.tensor([FMAX[fmt_a] / float(a.abs().max())], device="cuda")
+    sb = torch.tensor([448.0 / float(b.abs().max())], device="cuda")
+    a8, _ = ops.fp8_quantize(a.cuda(), sa, fmt_a)
+    b8, _ = ops.fp8_quantize(b.cuda(), sb, 0)
+    ref = (deq(a8, fmt_a) @ deq(b8, 0).t()) / (float(sa) * float(sb))
+    amax = torch.zeros(1, device="cuda")
+    if epi == "bias_gelu":
+        fq = 0
+        u_plain, f_plain = ops.gemm_fp8(a8, b8, sa, sb, bias=bias.cuda(), epilogue=L.EPI_BIAS_GELU)
+        val = torch.nn.functional.gelu(ref + bias, approximate="tanh")
+        qs = torch.tensor([448.0 / float(val.abs().max()) * 0.9], device="cuda")
+        C, q8, q8t = ops.gemm_fp8_emit(a8, b8, sa, sb, qs, epilogue=L.EPI_BIAS_GELU, bias=bias.cuda(), amax=amax)
+        # (alpha * acc + bias contracts to an fma in one epilogue and not in the other: a bf16 rounding may flip)
+        torch.testing.assert_close(C.float(), u_plain.float(), rtol=2.0 ** -7, atol=1e-6)
+        assert (C == u_plain).float().mean().item() > 0.99
+        plain = f_plain
+    else:
+        fq = 1
+        cs = torch.zeros(N, device="cuda")
+        cs_plain = torch.zeros(N, device="cuda")
+        plain = ops.gemm_fp8(a8, b8, sa, sb, fmt_a=fmt_a, aux=aux.cuda(), epilogue=L.EPI_DGELU, out2=cs_plain)
+        u = aux.float().requires_grad_(True)
+        torch.nn.functional.gelu(u, approximate="tanh").sum().backward()
+        val = ref * u.grad
+        qs = torch.tensor([57344.0 / float(val.abs().max()) * 0.9], device="cuda")
+        C, q8, q8t = ops.gemm_fp8_emit(a8, b8, sa, sb, qs, epilogue=L.EPI_DGELU, fmt_a=fmt_a, aux=aux.cuda(), colsum=cs, amax=amax)
+        assert C is None
+        torch.testing.assert_close(cs.cpu(), val.sum(0), rtol=2e-3, atol=2e-3 * float(val.abs().sum(0).max()))
+        torch.testing.assert_close(cs, cs_plain, rtol=1e-3, atol=1e-3 * float(cs_plain.abs().max()))
+    torch.cuda.synchronize()
+    assert torch.equal(q8t, q8.t().contiguous())
+    got = deq(q8, fq) / float(qs)
+    step = {0: 2.0 ** -3, 1: 2.0 ** -2}[fq]  # relative spacing of e4m3 / e5m2
+    tol = step * val.abs() + (2.0 ** -9 if fq == 0 else 2.0 ** -16) / float(qs) + 1e-6  # one step (a flipped rounding) + the subnormal step
+    assert ((got - val).abs() <= tol).all(), float(((got - val).abs() - tol).max())
+    # against the two-pass form (bf16 rounding first, then the quantiser): equal bytes almost everywhere
+    two_pass, _ = ops.fp8_quantize(plain, qs, fq)
+    same = (two_pass == q8).float().mean().item()
+    assert same > 0.9, same
+    torch.testing.assert_close(amax.cpu(), val.abs().max().reshape(1), rtol=2e-2, atol=0)
+
+
 # ------------------------------------------------------------------------------------------------ whole model, fp8 Linears
 XL2_CUT = dict(depth=2, hidden=1152, heads=16, patch=2, sample_size=32, in_channels=4, out_channels=4, cond_dim=1280)
 

@@ -314,14 +314,36 @@ int f8_fwd(const F8& f, const void* X, void* Xt_save, const void* W8, const floa
 }
 // backward of Y[M,N] = X[M,K] . W[N,K]^T: dW[N,K] += dY^T X, db[N] += colsum(dY), dX[M,K] = dY . W (optionally x gelu'(aux),
 // colsum of dX into dcol).  X8t = the transposed fp8 copy of the input saved by the forward (scale of role rx).
+// dY == NULL: the producer of dY already left its fp8 copies in dY8 / dY8t (f8_emit below) and its column sums where they belong.
+// rnext >= 0 (with aux): dX leaves only as fp8 (e5m2, scale / amax of role rnext) in q8 [M,K] / q8t [K,M] for the next f8_bwd.
 int f8_bwd(const F8& f, const void* dY, const void* X8t, const void* W8t, float* dW, float* db, void* dX, const void* aux,
-           float* dcol, int M, int N, int K, int rdy, int rx, int rw) {
-  RUN(f.quant(dY, UWU_BF16, M, N, rdy, f.dy8, f.dy8t, db, false));
-  RUN(uwu_gemm_fp8(f.dy8t, X8t, dW, nullptr, nullptr, nullptr, N, K, M, M, M, K, 0, UWU_FP8_E5M2, UWU_EPI_ACCUM,
+           float* dcol, int M, int N, int K, int rdy, int rx, int rw, const void* dY8 = nullptr, const void* dY8t = nullptr,
+           int rnext = -1, void* q8 = nullptr, void* q8t = nullptr) {
+  if (dY) {
+    RUN(f.quant(dY, UWU_BF16, M, N, rdy, f.dy8, f.dy8t, db, false));
+    dY8 = f.dy8;
+    dY8t = f.dy8t;
+  }
+  RUN(uwu_gemm_fp8(dY8t, X8t, dW, nullptr, nullptr, nullptr, N, K, M, M, M, K, 0, UWU_FP8_E5M2, UWU_EPI_ACCUM,
                    f.scale + rdy, f.scale + rx, f.wsc, f.wsc_bytes, f.st));
+  if (rnext >= 0)
+    return uwu_gemm_fp8_emit(dY8, W8t, nullptr, dcol, nullptr, aux, M, K, N, N, N, K, K, UWU_FP8_E5M2, UWU_EPI_DGELU, f.scale + rdy,
+                             f.scale + rw, q8, K, q8t, M, f.scale + rnext, f.amax + rnext, f.st);
   if (!dX) return UWU_OK;
-  return uwu_gemm_fp8(f.dy8, W8t, dX, dcol, nullptr, aux, M, K, N, N, N, K, K, UWU_FP8_E5M2, aux ? UWU_EPI_DGELU : UWU_EPI_NONE,
+  return uwu_gemm_fp8(dY8, W8t, dX, dcol, nullptr, aux, M, K, N, N, N, K, K, UWU_FP8_E5M2, aux ? UWU_EPI_DGELU : UWU_EPI_NONE,
                       f.scale + rdy, f.scale + rw, nullptr, 0, f.st);
+}
+// Delayed scaling knows the scale of a tensor before the tensor exists, so the two widest ones of a block -- gelu(u) (fc2's
+// input) and du (fc1's output gradient), [M, 4 D] each -- leave the GEMM that produces them as fp8 (row-major and transposed)
+// and the quantising pass over their bf16 copy (4 bytes of HBM traffic per element) is gone.  The first step (just-in-time
+// scaling: the scale comes from the tensor) keeps the two-pass form.  UWU_F8_EMIT=0: off (A/B).
+static bool f8_emit(const uwu_dit_desc& d) {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("UWU_F8_EMIT");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v == 1 && d.fp8 == 2;
 }
 
 // ---- small batches: weight gradients on a second stream --------------------------------------------------------------
@@ -475,6 +497,16 @@ int block_forward(const uwu_dit_desc& d, const Layout& L, const Ptrs& P, const F
                               P.lay(l, L.o_h2), P.lay<float>(l, L.o_m2), P.lay<float>(l, L.o_r2), B, T, D, d.ln_eps,
                               0, dt, st));
   if (d.fp8) {
+    if (f8_emit(d)) {  // fc1 writes u (bf16, for the backward pass) and gelu(u) as e4m3: row-major into dy8 (free in the forward), transposed into ft
+      const int r2 = f8.role(l, 2), r3 = f8.role(l, 3);
+      RUN(f8.quant(P.lay(l, L.o_h2), UWU_BF16, M, D, r2, f8.x8, P.lay(l, L.o_h2t), nullptr, false));
+      RUN(uwu_gemm_fp8_emit(f8.x8, f8.w(l, 2, false), P.lay(l, L.o_u), nullptr, w.fc1_b, nullptr, M, D4, D, D, D, D4, 0, UWU_FP8_E4M3,
+                            UWU_EPI_BIAS_GELU, f8.scale + r2, f8.scale + f8.role(l, 10), f8.dy8, D4, P.lay(l, L.o_ft), M, f8.scale + r3,
+                            f8.amax + r3, st));
+      RUN(uwu_gemm_fp8(f8.dy8, f8.w(l, 3, false), P.lay(l, L.o_y2), nullptr, w.fc2_b, nullptr, M, D, D4, D4, D4, D, 0, UWU_FP8_E4M3,
+                       UWU_EPI_BIAS, f8.scale + r3, f8.scale + f8.role(l, 11), nullptr, 0, st));
+      return UWU_OK;
+    }
     RUN(f8_fwd(f8, P.lay(l, L.o_h2), P.lay(l, L.o_h2t), f8.w(l, 2, false), w.fc1_b, P.lay(l, L.o_u), P.lay(l, L.o_f), M, D4, D, f8.role(l, 2), f8.role(l, 10), UWU_EPI_BIAS_GELU));
     RUN(f8_fwd(f8, P.lay(l, L.o_f), P.lay(l, L.o_ft), f8.w(l, 3, false), w.fc2_b, P.lay(l, L.o_y2), nullptr, M, D, D4, f8.role(l, 3), f8.role(l, 11), UWU_EPI_BIAS));
   } else {
@@ -623,10 +655,17 @@ extern "C" int uwu_dit_backward(const uwu_dit_desc* dp, const float* dout, void*
     // ---- MLP branch: y2 = fc2(gelu(fc1(h2)))
     if (d.fp8) {
       // fc2: dW2, db2, du = (dy.W2) * gelu'(u) with colsum(du) = fc1.bias gradient;  fc1: dW1, dh = du.W1
+      if (f8_emit(d)) {  // du leaves fc2's input-gradient GEMM as e5m2: row-major into x8 (free in the backward), transposed into dy8t
+        RUN(f8_bwd(f8, P.at(L.dy), P.lay(l, L.o_ft), f8.w(l, 3, true), g + w.off_fc2_w, g + w.off_fc2_b, nullptr, P.lay(l, L.o_u),
+                   g + w.off_fc1_b, M, D, D4, f8.role(l, 7), f8.role(l, 3), f8.role(l, 11), nullptr, nullptr, f8.role(l, 6), f8.x8, f8.dy8t));
+        RUN(f8_bwd(f8, nullptr, P.lay(l, L.o_h2t), f8.w(l, 2, true), g + w.off_fc1_w, nullptr, P.at(L.dh), nullptr, nullptr, M, D4, D,
+                   f8.role(l, 6), f8.role(l, 2), f8.role(l, 10), f8.x8, f8.dy8t));
+      } else {
       RUN(f8_bwd(f8, P.at(L.dy), P.lay(l, L.o_ft), f8.w(l, 3, true), g + w.off_fc2_w, g + w.off_fc2_b, P.at(L.du), P.lay(l, L.o_u),
                  g + w.off_fc1_b, M, D, D4, f8.role(l, 7), f8.role(l, 3), f8.role(l, 11)));
       RUN(f8_bwd(f8, P.at(L.du), P.lay(l, L.o_h2t), f8.w(l, 2, true), g + w.off_fc1_w, nullptr, P.at(L.dh), nullptr, nullptr, M, D4, D,
                  f8.role(l, 6), f8.role(l, 2), f8.role(l, 10)));
+      }
     } else {
     RUN(on_side(fk, 0, [&](void* s2, int k) {
       return lin_wgrad(P.at(L.dy), P.lay(l, L.o_f), g + w.off_fc2_w, M, D, D4, dt, s2, wsc + (size_t)k * L.wsc_bytes, L.wsc_bytes, g + w.off_fc2_b);

@@ -186,6 +186,12 @@ struct GemmArgs {
   // implicit-GEMM 3x3 convolution (padding 1): geometry of the gathered operand (CONV template parameters)
   int cH, cW, cC, cHo, cWo, cS;  // input H x W x C (channels-last), output Ho x Wo, stride
   const void* zero;              // >= 16 zero bytes in device memory: the source of padded / out-of-range pixels
+  // gemm_f8_kernel<EMIT>: the epilogue's result also leaves as fp8 bytes, row-major [M, N] and transposed [N, M]
+  void* q8;
+  void* q8t;
+  const float* q_scale;  // device float: q = sat(value * q_scale)
+  float* q_amax;         // optional: atomic max |value|
+  int ldq, ldqt;
 };
 
 // n / d and n % d for 0 <= n < 2^24 (exact in fp32): one multiply + a correction instead of an integer division
@@ -1757,7 +1763,164 @@ struct f8_t { unsigned char v; };
 template <> struct GT<f8_t> { static constexpr int EPC = 16; static constexpr int BK = 128; };
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
-template <typename TC, int EPI, int FA, bool PART>
+// EMIT (UWU_EPI_BIAS_GELU / UWU_EPI_DGELU): the operand the NEXT fp8 GEMMs contract over is produced here instead of by a
+// quantising pass over the bf16 result (quant.hip: 4 bytes of HBM traffic per element, 0.25 ms per [49152, 4608] tensor):
+//   BIAS_GELU: C = bf16 pre-activation (kept for the backward pass), q8 / q8t = e4m3(gelu(.) * q_scale)
+//   DGELU:     C2 = float[N] column sums if non-null, q8 / q8t = e5m2(result * q_scale); no bf16 copy (nothing reads it)
+// The 256 x 256 result tile is staged in LDS twice -- as it is and transposed (a 4 x 4 byte block sits in the dwords of four
+// neighbouring lanes: four quad broadcasts + two v_perm_b32 give each lane four consecutive ROWS of one column) -- and leaves
+// as whole 256-byte rows of both images.
+constexpr int F8Q_PITCH = 272;  // bytes per staged row (68 dwords: the dword writes of a wave spread over all 32 banks)
+constexpr int F8_EMIT_LDS = 2 * 256 * F8Q_PITCH + 2 * 256 * 4 + 64;
+
+template <int FMT>
+__device__ __forceinline__ unsigned f8_pack4(const f32x4& v, float s) {
+  const float mx = FMT == 0 ? 448.f : 57344.f;
+  float a = fminf(fmaxf(v[0] * s, -mx), mx), b = fminf(fmaxf(v[1] * s, -mx), mx);
+  float c = fminf(fmaxf(v[2] * s, -mx), mx), d = fminf(fmaxf(v[3] * s, -mx), mx);
+  int r;
+  if constexpr (FMT == 0) {
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+  } else {
+    r = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false);
+    r = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, r, true);
+  }
+  return (unsigned)r;
+}
+
+template <int EPI>
+__device__ __forceinline__ void f8_emit_epilogue(f32x4 (&acc)[8][4], const GemmArgs& g, char* smem, int m0, int n0, int tid) {
+  constexpr int FMT = EPI == UWU_EPI_DGELU ? 1 : 0;
+  constexpr int QP = F8Q_PITCH;
+  const int lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3, fr = lane & 15, fq = lane >> 4;
+  unsigned char* t_rm = reinterpret_cast<unsigned char*>(smem);
+  unsigned char* t_tr = t_rm + 256 * QP;
+  float* cs = reinterpret_cast<float*>(smem + 2 * 256 * QP);  // [2][256] column sums of the two wave rows
+  float* red = cs + 512;                                      // [8] per-wave |max|
+  bf16_t* C = static_cast<bf16_t*>(g.C);
+  const bf16_t* aux = static_cast<const bf16_t*>(g.aux);
+  float* colsum = EPI == UWU_EPI_DGELU ? reinterpret_cast<float*>(g.C2) : nullptr;
+  const float qs = g.q_scale[0];
+  const int m_w = m0 + wm * 128, n_w = n0 + wn * 64;
+  f32x4 bias[4], csum[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n_w + 16 * j + 4 * fq;
+    bias[j] = (EPI == UWU_EPI_BIAS_GELU && n < g.N) ? load4(g.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    csum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  auto aux_row = [&](int i, uint2 (&dst)[4]) {
+    const int m = m_w + 16 * i + fr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n_w + 16 * j + 4 * fq;
+      dst[j] = (m < g.M && n < g.N) ? *reinterpret_cast<const uint2*>(aux + (int64_t)m * g.ldaux + n) : uint2{0u, 0u};
+    }
+  };
+  uint2 ar[2][4];
+  if constexpr (EPI == UWU_EPI_DGELU) aux_row(0, ar[0]);
+  __syncthreads();  // every wave has left the K loop: the stages are free
+  const bool odd = fq & 1;
+  const int kq = lane & 3;
+  const unsigned sel = 0x0c0c0400u + (unsigned)kq * 0x0101u;
+  float mx = 0.f;
+  auto pack = [](const f32x4& v) {
+    bf16x4 b = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    return *reinterpret_cast<uint2*>(&b);
+  };
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int ml = wm * 128 + 16 * i + fr, m = m0 + ml;
+    const bool mok = m < g.M;
+    __builtin_amdgcn_sched_barrier(0);  // (keeps the unrolled rows apart: hoisted aux loads of later rows spilled registers)
+    if constexpr (EPI == UWU_EPI_DGELU)
+      if (i + 1 < 8) aux_row(i + 1, ar[(i + 1) & 1]);
+    f32x4 v[4], o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n_w + 16 * j + 4 * fq;
+      v[j] = acc[i][j];
+      if constexpr (EPI == UWU_EPI_BIAS_GELU) {
+        v[j] = v[j] + bias[j];
+        o[j] = gelu_tanh_f4(v[j]);
+      } else {
+        const bf16x4 u = *reinterpret_cast<const bf16x4*>(&ar[i & 1][j]);
+        v[j] = v[j] * dgelu_tanh_f4(f32x4{(float)u[0], (float)u[1], (float)u[2], (float)u[3]});
+        o[j] = v[j];
+        if (mok && n < g.N) csum[j] = csum[j] + v[j];
+      }
+      if (!(mok && n < g.N)) o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fabsf(o[j][e]));
+      asm volatile("" : "+v"(mx));  // (taken now: left to the optimiser the max chain sank to the end of the tile and o[] was spilled)
+      const unsigned pk = f8_pack4<FMT>(o[j], qs);
+      const int nl = wn * 64 + 16 * j + 4 * fq;
+      *reinterpret_cast<unsigned*>(t_rm + ml * QP + nl) = pk;
+      // 4 x 4 byte transpose inside the quad of lanes that holds rows 4 (fr / 4) .. + 3 of these four columns
+      const int pi = (int)pk;
+      const unsigned d0 = (unsigned)__builtin_amdgcn_update_dpp(0, pi, 0x00, 0xF, 0xF, false);
+      const unsigned d1 = (unsigned)__builtin_amdgcn_update_dpp(0, pi, 0x55, 0xF, 0xF, false);
+      const unsigned d2 = (unsigned)__builtin_amdgcn_update_dpp(0, pi, 0xAA, 0xF, 0xF, false);
+      const unsigned d3 = (unsigned)__builtin_amdgcn_update_dpp(0, pi, 0xFF, 0xF, 0xF, false);
+      const unsigned lo = __builtin_amdgcn_perm(d1, d0, sel), hi = __builtin_amdgcn_perm(d3, d2, sel);
+      *reinterpret_cast<unsigned*>(t_tr + (nl + kq) * QP + (ml & ~3)) = lo | (hi << 16);
+      __builtin_amdgcn_sched_barrier(0);  // (fragment by fragment: the scheduler otherwise kept every o[] alive for the max chain and spilled)
+    }
+    if constexpr (EPI == UWU_EPI_BIAS_GELU) {  // bf16 pre-activation: paired 16-byte stores as epilogue_tile (8 consecutive columns per lane)
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+        typedef unsigned su32x2 __attribute__((ext_vector_type(2)));
+        typedef unsigned su32x4 __attribute__((ext_vector_type(4)));
+        const uint2 p0 = pack(v[2 * jp]), p1 = pack(v[2 * jp + 1]);
+        const su32x2 sx = __builtin_amdgcn_permlane16_swap(p0.x, p1.x, false, false);
+        const su32x2 sy = __builtin_amdgcn_permlane16_swap(p0.y, p1.y, false, false);
+        const int nb = n_w + 32 * jp;
+        const int n = odd ? nb + 16 + 4 * (fq - 1) : nb + 4 * fq;
+        if (mok && n < g.N) {
+          const su32x4 ov = su32x4{sx[0], sy[0], sx[1], sy[1]};
+          su32x4* ptr = reinterpret_cast<su32x4*>(C + (int64_t)m * g.ldc + n);
+          __builtin_nontemporal_store(ov, ptr);  // read again in the backward pass only
+        }
+      }
+    }
+  }
+  if (colsum) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 t = csum[j];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] = row16_sum(t[e]);
+      if (fr == 0) store4(cs + wm * 256 + wn * 64 + 16 * j + 4 * fq, t);
+    }
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  if (colsum && tid < 256 && n0 + tid < g.N) atomicAdd(colsum + n0 + tid, cs[tid] + cs[256 + tid]);
+  if (g.q_amax && tid == 0) {
+    float a = red[0];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) a = fmaxf(a, red[w]);
+    // (look first: atomics on one address serialise; almost every workgroup can skip it -- quant.hip)
+    const unsigned cur = __hip_atomic_load(reinterpret_cast<unsigned*>(g.q_amax), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__float_as_uint(a) > cur) atomicMax(reinterpret_cast<unsigned*>(g.q_amax), __float_as_uint(a));
+  }
+  // both images leave as whole rows: 16 lanes x 16 bytes = one 256-byte row per 16 threads, 32 rows per pass
+  unsigned char* q8 = static_cast<unsigned char*>(g.q8);
+  unsigned char* q8t = static_cast<unsigned char*>(g.q8t);
+  const int r0 = tid >> 4, c16 = 16 * (tid & 15);
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int r = 32 * p + r0;
+    if (q8 && m0 + r < g.M && n0 + c16 < g.N)
+      *reinterpret_cast<uint4*>(q8 + (int64_t)(m0 + r) * g.ldq + n0 + c16) = *reinterpret_cast<const uint4*>(t_rm + r * QP + c16);
+    if (q8t && n0 + r < g.N && m0 + c16 < g.M)
+      *reinterpret_cast<uint4*>(q8t + (int64_t)(n0 + r) * g.ldqt + m0 + c16) = *reinterpret_cast<const uint4*>(t_tr + r * QP + c16);
+  }
+}
+
+template <typename TC, int EPI, int FA, bool PART, bool EMIT = false>
 __global__ void __launch_bounds__(512, 2) gemm_f8_kernel(const GemmArgs g, const float* __restrict__ scale_a,
                                                          const float* __restrict__ scale_b) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1846,6 +2009,8 @@ __global__ void __launch_bounds__(512, 2) gemm_f8_kernel(const GemmArgs g, const
         if (m < g.M && n < g.N) store4(P + (int64_t)m * g.N + n, acc[i][j]);
       }
     }
+  } else if constexpr (EMIT) {
+    f8_emit_epilogue<EPI>(acc, g, smem, m0, n0, tid);
   } else {
     EpiPre<bf16_t, 8, 4> pre;
     epi_prefetch<bf16_t, 8, 4, EPI>(pre, g, m0 + wm * 128, n0 + wn * 64, fr, fq);
@@ -2313,6 +2478,25 @@ int launch_f8(GemmArgs g, const float* sa, const float* sb, hipStream_t st) {
   UWU_LAUNCH_CHECK("gemm_f8");
   return UWU_OK;
 }
+template <int EPI, int FA>
+int launch_f8_emit(GemmArgs g, const float* sa, const float* sb, hipStream_t st) {
+  auto kern = gemm_f8_kernel<bf16_t, EPI, FA, false, true>;
+  constexpr int LDS = F8_EMIT_LDS > 2 * 4 * TILE_BYTES ? F8_EMIT_LDS : 2 * 4 * TILE_BYTES;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_done = true;
+  }
+  g.tiles_m = (g.M + 255) / 256;
+  g.tiles_n = (g.N + 255) / 256;
+  UwuProfScope prof(st);
+  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(512), LDS, st, g, sa, sb);
+  // bytes: operands once, the bf16 output (if any), the dGELU aux, both fp8 images
+  double by = (double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N * ((g.C ? 2 : 0) + (g.aux ? 2 : 0) + (g.q8 ? 1 : 0) + (g.q8t ? 1 : 0));
+  prof.done(gemm_tag(g, false, false), 0, 2.0 * g.M * g.N * g.K, by);
+  UWU_LAUNCH_CHECK("gemm_f8(emit)");
+  return UWU_OK;
+}
 // number of K slices for an fp8 weight gradient: enough workgroups for ~2 rounds of the chip, >= 4 K-steps per slice
 int f8_split(int tiles, int steps) {
   int split = (512 + tiles - 1) / tiles;
@@ -2474,6 +2658,37 @@ extern "C" int uwu_gemm_fp8(const void* A, const void* B, void* C, void* C2, con
 #undef F8_CASE
   uwu_set_error("gemm_fp8: epilogue %d not available", epilogue);
   return UWU_EINVAL;
+}
+
+extern "C" int uwu_gemm_fp8_emit(const void* A, const void* B, void* C, float* colsum, const float* bias, const void* aux,
+                                 int M, int N, int K, int lda, int ldb, int ldc, int ldaux, int fmt_a, int epilogue,
+                                 const float* scale_a, const float* scale_b, void* q8, int ldq, void* q8t, int ldqt,
+                                 const float* q_scale, float* q_amax, void* stream) {
+  UWU_CHECK_ARG(A && B && scale_a && scale_b && q_scale && (q8 || q8t), "gemm_fp8_emit: null operand");
+  UWU_CHECK_ARG(epilogue == UWU_EPI_BIAS_GELU || epilogue == UWU_EPI_DGELU, "gemm_fp8_emit: epilogue %d not available", epilogue);
+  UWU_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % 128 == 0, "gemm_fp8_emit: K=%d must be a positive multiple of 128", K);
+  UWU_CHECK_ARG(M % 16 == 0 && N % 16 == 0, "gemm_fp8_emit: M=%d and N=%d must be multiples of 16", M, N);
+  UWU_CHECK_ARG(fmt_a == UWU_FP8_E4M3 || fmt_a == UWU_FP8_E5M2, "gemm_fp8_emit: bad operand format %d", fmt_a);
+  UWU_CHECK_ARG((((uintptr_t)A | (uintptr_t)B) & 15) == 0 && lda % 16 == 0 && ldb % 16 == 0 && lda >= K && ldb >= K,
+                "gemm_fp8_emit: operands must be 16-byte aligned with leading dimensions that are multiples of 16");
+  UWU_CHECK_ARG(!C || (ldc % 8 == 0 && ldc >= N && ((uintptr_t)C & 15) == 0), "gemm_fp8_emit: C / ldc misaligned");
+  UWU_CHECK_ARG(!q8 || (ldq % 16 == 0 && ldq >= N && ((uintptr_t)q8 & 15) == 0), "gemm_fp8_emit: q8 / ldq misaligned");
+  UWU_CHECK_ARG(!q8t || (ldqt % 16 == 0 && ldqt >= M && ((uintptr_t)q8t & 15) == 0), "gemm_fp8_emit: q8t / ldqt misaligned");
+  GemmArgs g{};
+  g.A = A; g.B = B; g.C = C; g.C2 = colsum; g.bias = bias; g.aux = aux;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux; g.epi = epilogue;
+  g.q8 = q8; g.q8t = q8t; g.q_scale = q_scale; g.q_amax = q_amax; g.ldq = ldq; g.ldqt = ldqt;
+  g.wide = 1;
+  hipStream_t st = (hipStream_t)stream;
+  if (epilogue == UWU_EPI_BIAS_GELU) {
+    UWU_CHECK_ARG(C && bias && ((uintptr_t)bias & 15) == 0 && !colsum, "gemm_fp8_emit: BIAS_GELU needs C (the pre-activation) and bias");
+    return fmt_a == UWU_FP8_E5M2 ? launch_f8_emit<UWU_EPI_BIAS_GELU, 1>(g, scale_a, scale_b, st)
+                                 : launch_f8_emit<UWU_EPI_BIAS_GELU, 0>(g, scale_a, scale_b, st);
+  }
+  UWU_CHECK_ARG(aux && ldaux % 4 == 0 && ldaux >= N && ((uintptr_t)aux & 7) == 0, "gemm_fp8_emit: aux missing/misaligned");
+  UWU_CHECK_ARG(!C, "gemm_fp8_emit: DGELU emits fp8 only (C must be NULL)");
+  return fmt_a == UWU_FP8_E5M2 ? launch_f8_emit<UWU_EPI_DGELU, 1>(g, scale_a, scale_b, st)
+                               : launch_f8_emit<UWU_EPI_DGELU, 0>(g, scale_a, scale_b, st);
 }
 
 extern "C" int uwu_gemm(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux, int M,

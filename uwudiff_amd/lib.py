@@ -71,6 +71,8 @@ _SIGS = {
     "uwu_fp8_amax": (c_int, [P, c_int, c_int64, P, P]),
     "uwu_fp8_update_scales": (c_int, [P, P, P, c_int, c_float, P]),
     "uwu_fp8_quantize": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, P, P]),
+    "uwu_gemm_fp8_emit": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P, c_int, P,
+                                  P, P]),
     "uwu_gemm_wgrad_scratch_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
     "uwu_gemm_wgrad": (c_int, [P, P, P, P] + [c_int] * 8 + [P, ctypes.c_size_t, P]),
     "uwu_gemm_prof_enable": (c_int, [c_int]),

@@ -303,6 +303,22 @@ def gemm_fp8(a8, b8, scale_a, scale_b, *, fmt_a=FP8_E4M3, bias=None, aux=None, e
     return (out, out2) if out2 is not None and epilogue == L.EPI_BIAS_GELU else out
 
 
+def gemm_fp8_emit(a8, b8, scale_a, scale_b, q_scale, *, epilogue, fmt_a=FP8_E4M3, bias=None, aux=None, colsum=None, amax=None,
+                  rowmajor=True, transposed=True):
+    """The fp8 GEMM whose epilogue leaves its result as the fp8 operand of the next GEMMs (no quantising pass):
+    EPI_BIAS_GELU -> (bf16 pre-activation, e4m3 gelu [M,N], its transpose [N,M]); EPI_DGELU -> (None, e5m2 [M,N], [N,M])."""
+    M, K = a8.shape
+    N = b8.shape[0]
+    assert a8.dtype == torch.uint8 and b8.dtype == torch.uint8 and b8.shape[1] == K
+    C = torch.empty(M, N, device=a8.device, dtype=torch.bfloat16) if epilogue == L.EPI_BIAS_GELU else None
+    q8 = torch.empty(M, N, device=a8.device, dtype=torch.uint8) if rowmajor else None
+    q8t = torch.empty(N, M, device=a8.device, dtype=torch.uint8) if transposed else None
+    L.call("uwu_gemm_fp8_emit", L.ptr(a8), L.ptr(b8), L.ptr(C), L.ptr(colsum), L.ptr(bias), L.ptr(aux), M, N, K, a8.stride(0),
+           b8.stride(0), N, aux.stride(0) if aux is not None else 0, fmt_a, epilogue, L.ptr(scale_a), L.ptr(scale_b), L.ptr(q8), N,
+           L.ptr(q8t), M, L.ptr(q_scale), L.ptr(amax), L.stream())
+    return C, q8, q8t
+
+
 # ---------------------------------------------------------------------------------------------------- RoPE in attention
 def axial_rope_table(pos, fh, fw, H, d):
     """Factor table m [T, H*d] (fp32) of the reference's axial RoPE for shared positions pos [T, 2]."""
