@@ -294,6 +294,13 @@ int uwu_colsum_batched(const void* X, int dtype, int batch, int M, int N, int ld
 int uwu_add_ln_modulate_fwd(const void* x_in, const void* y, const float* gate, const float* shift,
                             const float* scale, int mod_ld, void* x_out, void* h, float* mean, float* rstd,
                             int B, int T, int D, float eps, int affine, int dtype, void* stream);
+/* fp8 mode, delayed scaling: the same LayerNorm whose output leaves ONLY as the e4m3 operand of the next GEMMs -- q8 [B*T, D]
+ * (contraction over D) and q8t [D, B*T] (the weight gradient's contraction over the tokens) = sat(h * q_scale[0]); q_amax
+ * (optional) receives max |h|.  bf16 tensors, per-sample shift / scale required, B*T a multiple of 64, D <= 1536. */
+int uwu_add_ln_modulate_fwd_q8(const void* x_in, const void* y, const float* gate, const float* shift, const float* scale,
+                               int mod_ld, void* x_out, void* q8, int ldq, void* q8t, int ldqt, const float* q_scale,
+                               float* q_amax, float* mean, float* rstd, int B, int T, int D, float eps, void* stream);
+
 
 /* Backward of the above, fused with the residual/gate backward of the branch that feeds x:
  *   dx_out = dx_in + LN_bwd(dh * (1+scale_b))        (dx_in may be NULL for the last norm)

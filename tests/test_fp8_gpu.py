@@ -195,6 +195,42 @@ def test_gemm_fp8_emit_matches_quantised_result(epi, M, N, K):
     torch.testing.assert_close(amax.cpu(), val.abs().max().reshape(1), rtol=2e-2, atol=0)
 
 
+@pytest.mark.parametrize("D,B,T,with_y", [(1152, 3, 256, True), (384, 2, 96, False), (768, 1, 320, True)])
+def test_layernorm_emits_fp8_images(D, B, T, with_y):
+    """fp8 mode: LayerNorm + modulate writing the next GEMM's e4m3 operand (row-major + transposed) instead of bf16 h.
+    Residual stream and statistics bit-equal to the plain kernel's; the bytes = RNE quantisation of the fp32 output (within one
+    e4m3 step where a rounding flips); the transposed image is the exact transpose; amax recorded.  Rows straddle samples."""
+    from uwudiff_amd import ops
+
+    torch.manual_seed(21)
+    M, ML = B * T, 3 * D + 8
+    x_in = torch.randn(M, D).bfloat16().cuda()
+    y = torch.randn(M, D).bfloat16().cuda() if with_y else None
+    mod = (torch.randn(B, ML) * 0.5).cuda()
+    g, sh, sc = mod[:, 0:D], mod[:, D:2 * D], mod[:, 2 * D:3 * D]
+    kw = dict(shift=sh, scale=sc, mod_ld=ML)
+    if with_y:
+        kw.update(y=y, gate=g)
+    x_out, h, mean, rstd = ops.add_ln_modulate_fwd(x_in, B, T, **kw)
+    xo = x_out.float()
+    href = torch.nn.functional.layer_norm(xo, (D,), eps=1e-6) * (1 + sc.repeat_interleave(T, 0)) + sh.repeat_interleave(T, 0)
+    qs = torch.tensor([448.0 / float(href.abs().max()) * 0.9], device="cuda")
+    amax = torch.zeros(1, device="cuda")
+    x_out2, q8, q8t, mean2, rstd2 = ops.add_ln_modulate_fwd_q8(x_in, B, T, qs, amax=amax, **kw)
+    torch.cuda.synchronize()
+    if with_y:
+        assert torch.equal(x_out2, x_out)
+    assert torch.equal(mean2, mean) and torch.equal(rstd2, rstd)
+    assert torch.equal(q8t, q8.t().contiguous())
+    got = deq(q8, 0) / float(qs)
+    val = href.cpu()
+    tol = 2.0 ** -3 * val.abs() + 2.0 ** -9 / float(qs) + 1e-6
+    assert ((got - val).abs() <= tol).all(), float(((got - val).abs() - tol).max())
+    two_pass, _ = ops.fp8_quantize(h, qs, 0)
+    assert (two_pass == q8).float().mean().item() > 0.9
+    torch.testing.assert_close(amax.cpu(), val.abs().max().reshape(1), rtol=1e-2, atol=0)
+
+
 # ------------------------------------------------------------------------------------------------ whole model, fp8 Linears
 XL2_CUT = dict(depth=2, hidden=1152, heads=16, patch=2, sample_size=32, in_channels=4, out_channels=4, cond_dim=1280)
 

@@ -308,7 +308,8 @@ struct F8 {
 int f8_fwd(const F8& f, const void* X, void* Xt_save, const void* W8, const float* bias, void* Y, void* Y2, int M, int N, int K,
            int rx, int rw, int epi) {
   // one pass over X: the row-major copy for this GEMM and the transposed copy the weight gradient will contract over
-  RUN(f.quant(X, UWU_BF16, M, K, rx, f.x8, Xt_save, nullptr, false));
+  // (X == NULL: the producer of X already left both, ln_fwd_q8 below)
+  if (X) RUN(f.quant(X, UWU_BF16, M, K, rx, f.x8, Xt_save, nullptr, false));
   return uwu_gemm_fp8(f.x8, W8, Y, Y2, bias, nullptr, M, N, K, K, K, N, 0, UWU_FP8_E4M3, epi, f.scale + rx, f.scale + rw,
                       nullptr, 0, f.st);
 }
@@ -337,6 +338,21 @@ int f8_bwd(const F8& f, const void* dY, const void* X8t, const void* W8t, float*
 // input) and du (fc1's output gradient), [M, 4 D] each -- leave the GEMM that produces them as fp8 (row-major and transposed)
 // and the quantising pass over their bf16 copy (4 bytes of HBM traffic per element) is gone.  The first step (just-in-time
 // scaling: the scale comes from the tensor) keeps the two-pass form.  UWU_F8_EMIT=0: off (A/B).
+static bool f8_emit(const uwu_dit_desc& d);
+// h = LN(x_in + gate * y) * (1 + scale) + shift feeding ONLY an fp8 Linear: with delayed scaling the LayerNorm kernel writes the
+// e4m3 images itself (row-major into the shared x8, transposed into the layer's saved copy) and no bf16 h exists.
+// Returns 1 when it did (the caller then passes X = NULL to f8_fwd), 0 when the bf16 form ran, < 0 on error.
+static int ln_fwd_f8(const uwu_dit_desc& d, const F8& f, const void* x_in, const void* y, const float* gate, const float* shift,
+                     const float* scale, int ML, void* x_out, void* h, void* h8t, int role, float* mean, float* rstd, void* st) {
+  const int64_t M = (int64_t)d.B * d.T;
+  if (f8_emit(d) && d.D <= 1536 && M % 64 == 0) {
+    const int rc = uwu_add_ln_modulate_fwd_q8(x_in, y, gate, shift, scale, ML, x_out, f.x8, d.D, h8t, (int)M, f.scale + role,
+                                              f.amax + role, mean, rstd, d.B, d.T, d.D, d.ln_eps, st);
+    return rc == UWU_OK ? 1 : rc;
+  }
+  const int rc = uwu_add_ln_modulate_fwd(x_in, y, gate, shift, scale, ML, x_out, h, mean, rstd, d.B, d.T, d.D, d.ln_eps, 0, d.dtype, st);
+  return rc == UWU_OK ? 0 : rc;
+}
 static bool f8_emit(const uwu_dit_desc& d) {
   static int v = -1;
   if (v < 0) {
@@ -469,6 +485,18 @@ int block_forward(const uwu_dit_desc& d, const Layout& L, const Ptrs& P, const F
   const float* m = mod + (int64_t)l * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
   void* x0 = P.lay(l, L.o_x0);
   // LN1 (+ pending MLP branch of the previous layer: x0 = x1_prev + gate_mlp_prev * y2_prev)
+  int h1q = 0, h2q = 0;  // fp8 mode: 1 = the LayerNorm left its output as fp8 (no bf16 h1 / h2)
+  if (d.fp8) {
+    if (l == 0 || recompute) {
+      h1q = ln_fwd_f8(d, f8, x0, nullptr, nullptr, m + 0, m + D, ML, x0, P.lay(l, L.o_h1), P.lay(l, L.o_h1t), f8.role(l, 0),
+                      P.lay<float>(l, L.o_m1), P.lay<float>(l, L.o_r1), st);
+    } else {
+      const float* mp = mod + (int64_t)(l - 1) * 6 * D;
+      h1q = ln_fwd_f8(d, f8, P.lay(l - 1, L.o_x1), P.lay(l - 1, L.o_y2), mp + 5 * D, m + 0, m + D, ML, x0, P.lay(l, L.o_h1),
+                      P.lay(l, L.o_h1t), f8.role(l, 0), P.lay<float>(l, L.o_m1), P.lay<float>(l, L.o_r1), st);
+    }
+    if (h1q < 0) return h1q;
+  } else
   if (l == 0 || recompute) {  // (recompute: x0 of this block was kept; its statistics come out the same)
     RUN(uwu_add_ln_modulate_fwd(x0, nullptr, nullptr, m + 0, m + D, ML, x0, P.lay(l, L.o_h1),
                                 P.lay<float>(l, L.o_m1), P.lay<float>(l, L.o_r1), B, T, D, d.ln_eps, 0, dt, st));
@@ -478,7 +506,7 @@ int block_forward(const uwu_dit_desc& d, const Layout& L, const Ptrs& P, const F
                                 P.lay(l, L.o_h1), P.lay<float>(l, L.o_m1), P.lay<float>(l, L.o_r1), B, T, D,
                                 d.ln_eps, 0, dt, st));
   }
-  if (d.fp8) RUN(f8_fwd(f8, P.lay(l, L.o_h1), P.lay(l, L.o_h1t), f8.w(l, 0, false), w.qkv_b, P.lay(l, L.o_qkv), nullptr, M, D3, D, f8.role(l, 0), f8.role(l, 8), UWU_EPI_BIAS));
+  if (d.fp8) RUN(f8_fwd(f8, h1q ? nullptr : P.lay(l, L.o_h1), P.lay(l, L.o_h1t), f8.w(l, 0, false), w.qkv_b, P.lay(l, L.o_qkv), nullptr, M, D3, D, f8.role(l, 0), f8.role(l, 8), UWU_EPI_BIAS));
   else RUN(lin_fwd(P.lay(l, L.o_h1), w.qkv_w, w.qkv_b, P.lay(l, L.o_qkv), nullptr, M, D3, D, dt, dt, UWU_EPI_BIAS, st));
   char* qkv = P.lay<char>(l, L.o_qkv);
   if (d.rope) {  // this layer's factor table, then attention with q / k rotated while they are staged
@@ -493,13 +521,18 @@ int block_forward(const uwu_dit_desc& d, const Layout& L, const Ptrs& P, const F
   if (d.fp8) RUN(f8_fwd(f8, P.lay(l, L.o_ao), P.lay(l, L.o_aot), f8.w(l, 1, false), w.o_b, P.lay(l, L.o_y1), nullptr, M, D, D, f8.role(l, 1), f8.role(l, 9), UWU_EPI_BIAS));
   else RUN(lin_fwd(P.lay(l, L.o_ao), w.o_w, w.o_b, P.lay(l, L.o_y1), nullptr, M, D, D, dt, dt, UWU_EPI_BIAS, st));
   // x1 = x0 + gate_msa * y1 ; h2 = LN(x1)*(1+scale_mlp)+shift_mlp
+  if (d.fp8) {
+    h2q = ln_fwd_f8(d, f8, x0, P.lay(l, L.o_y1), m + 2 * D, m + 3 * D, m + 4 * D, ML, P.lay(l, L.o_x1), P.lay(l, L.o_h2),
+                    P.lay(l, L.o_h2t), f8.role(l, 2), P.lay<float>(l, L.o_m2), P.lay<float>(l, L.o_r2), st);
+    if (h2q < 0) return h2q;
+  } else
   RUN(uwu_add_ln_modulate_fwd(x0, P.lay(l, L.o_y1), m + 2 * D, m + 3 * D, m + 4 * D, ML, P.lay(l, L.o_x1),
                               P.lay(l, L.o_h2), P.lay<float>(l, L.o_m2), P.lay<float>(l, L.o_r2), B, T, D, d.ln_eps,
                               0, dt, st));
   if (d.fp8) {
     if (f8_emit(d)) {  // fc1 writes u (bf16, for the backward pass) and gelu(u) as e4m3: row-major into dy8 (free in the forward), transposed into ft
       const int r2 = f8.role(l, 2), r3 = f8.role(l, 3);
-      RUN(f8.quant(P.lay(l, L.o_h2), UWU_BF16, M, D, r2, f8.x8, P.lay(l, L.o_h2t), nullptr, false));
+      if (!h2q) RUN(f8.quant(P.lay(l, L.o_h2), UWU_BF16, M, D, r2, f8.x8, P.lay(l, L.o_h2t), nullptr, false));
       RUN(uwu_gemm_fp8_emit(f8.x8, f8.w(l, 2, false), P.lay(l, L.o_u), nullptr, w.fc1_b, nullptr, M, D4, D, D, D, D4, 0, UWU_FP8_E4M3,
                             UWU_EPI_BIAS_GELU, f8.scale + r2, f8.scale + f8.role(l, 10), f8.dy8, D4, P.lay(l, L.o_ft), M, f8.scale + r3,
                             f8.amax + r3, st));
@@ -507,7 +540,7 @@ int block_forward(const uwu_dit_desc& d, const Layout& L, const Ptrs& P, const F
                        UWU_EPI_BIAS, f8.scale + r3, f8.scale + f8.role(l, 11), nullptr, 0, st));
       return UWU_OK;
     }
-    RUN(f8_fwd(f8, P.lay(l, L.o_h2), P.lay(l, L.o_h2t), f8.w(l, 2, false), w.fc1_b, P.lay(l, L.o_u), P.lay(l, L.o_f), M, D4, D, f8.role(l, 2), f8.role(l, 10), UWU_EPI_BIAS_GELU));
+    RUN(f8_fwd(f8, h2q ? nullptr : P.lay(l, L.o_h2), P.lay(l, L.o_h2t), f8.w(l, 2, false), w.fc1_b, P.lay(l, L.o_u), P.lay(l, L.o_f), M, D4, D, f8.role(l, 2), f8.role(l, 10), UWU_EPI_BIAS_GELU));
     RUN(f8_fwd(f8, P.lay(l, L.o_f), P.lay(l, L.o_ft), f8.w(l, 3, false), w.fc2_b, P.lay(l, L.o_y2), nullptr, M, D, D4, f8.role(l, 3), f8.role(l, 11), UWU_EPI_BIAS));
   } else {
     RUN(lin_fwd(P.lay(l, L.o_h2), w.fc1_w, w.fc1_b, P.lay(l, L.o_u), P.lay(l, L.o_f), M, D4, D, dt, dt,

@@ -195,6 +195,151 @@ __global__ void __launch_bounds__(256) add_ln_mod_fwd16_kernel(const T* __restri
   }
 }
 
+// ---- fp8 mode (BASELINE config 5), delayed scaling: the LayerNorm output leaves as the fp8 operand of the next GEMMs -------
+// h is consumed only by a Linear (row-major e4m3, contraction over D) and by that Linear's weight gradient (transposed,
+// contraction over the tokens), so instead of bf16 h + a quantising pass (quant.hip: 2 + 2 bytes per element) this kernel writes
+// both fp8 images itself.  One workgroup = 64 consecutive rows, 8 waves x 8 rows, the loads of the next row in flight while a
+// row is reduced.  A lane owns 8 columns per 512-column pass: its 8 bytes go to global memory (row-major image) and into an
+// LDS copy of the tile [64 rows][D] (8-byte writes, conflict-free).  After the last row a thread takes 4 columns x 16 rows of
+// that copy -- 16 dwords, consecutive lanes consecutive dwords -- transposes the four 4 x 4 byte blocks with v_perm_b32 and
+// stores 16 contiguous bytes of each of its 4 columns of the transposed image (64-byte runs along the tokens per tile).
+__device__ __forceinline__ unsigned q8_pack4(float a, float b, float c, float d, float s) {
+  a = fminf(fmaxf(a * s, -448.f), 448.f);
+  b = fminf(fmaxf(b * s, -448.f), 448.f);
+  c = fminf(fmaxf(c * s, -448.f), 448.f);
+  d = fminf(fmaxf(d * s, -448.f), 448.f);
+  int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+}
+
+template <int MAX_IT, int NW>  // NW waves x 8 rows = one tile
+__global__ void __launch_bounds__(64 * NW, 4) add_ln_mod_fwd_q8_kernel(
+    const bf16_t* __restrict__ x_in, const bf16_t* __restrict__ y, const float* __restrict__ gate,
+    const float* __restrict__ shift, const float* __restrict__ scale, int mod_ld, bf16_t* __restrict__ x_out,
+    unsigned char* __restrict__ q8, int ldq, unsigned char* __restrict__ q8t, int ldqt, const float* __restrict__ q_scale,
+    float* __restrict__ q_amax, float* __restrict__ mean_o, float* __restrict__ rstd_o, int M, int T_tok, int D, float eps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char img[];  // [8 NW][D + 8] fp8 bytes
+  __shared__ float red[NW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nit = (D + 511) >> 9;
+  const int row0 = blockIdx.x * 8 * NW;
+  const int pitch = D + 8;  // (rows 16 apart: banks 32 apart)
+  const float qs = q_scale[0];
+  float mx = 0.f;
+  // the loads of row r + 1 are issued before row r is reduced (two rows in flight per wave: with one, the dependent chain
+  // load -> two wave reductions -> store of each row left the 16 waves of a CU short of the bytes in flight HBM needs)
+  // (y has one buffer: it is consumed by the first pass over a row, and the next row is fetched right after that pass)
+  bf16x8 xr[2][MAX_IT], yr[MAX_IT];
+  auto fetch = [&](int r, int buf) {
+    const int64_t off = (int64_t)(row0 + 8 * wave + r) * D;
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it) {
+      const int d = it * 512 + lane * 8;
+      if (it < nit && d < D) {
+        xr[buf][it] = raw8_nt(x_in + off + d);
+        if (y) yr[it] = raw8_nt(y + off + d);
+      }
+    }
+  };
+  fetch(0, 0);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int buf = r & 1;
+    const int row = row0 + 8 * wave + r;
+    const int b = row / T_tok;
+    const int64_t off = (int64_t)row * D;
+    bf16x8 v[MAX_IT];  // the residual-stream values (exactly bf16) stay packed between the passes
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it) {
+      const int d = it * 512 + lane * 8;
+      if (it < nit && d < D) {
+        f32x8 xv = unpack8(xr[buf][it]);
+        v[it] = xr[buf][it];
+        if (y) {
+          const f32x8 yv = unpack8(yr[it]), gv = load8(gate + (int64_t)b * mod_ld + d);
+          xv = xv + gv * yv;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[it][e] = (bf16_t)xv[e];
+          typedef unsigned nu32x4 __attribute__((ext_vector_type(4)));
+          __builtin_nontemporal_store(*reinterpret_cast<nu32x4*>(&v[it]), reinterpret_cast<nu32x4*>(x_out + off + d));
+          xv = unpack8(v[it]);
+        }
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) s += xv[e];
+      }
+    }
+    if (r + 1 < 8) fetch(r + 1, buf ^ 1);
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it) {
+      const int d = it * 512 + lane * 8;
+      if (it < nit && d < D) {
+        const f32x8 xv = unpack8(v[it]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float c = xv[e] - mean;
+          q += c * c;
+        }
+      }
+    }
+    const float var = wave_sum(q) / (float)D;
+    const float rstd = 1.f / sqrtf(var + eps);
+    if (lane == 0) {
+      mean_o[row] = mean;
+      rstd_o[row] = rstd;
+    }
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it) {
+      const int d = it * 512 + lane * 8;
+      if (it < nit && d < D) {
+        f32x8 o;
+        const f32x8 sc = load8(scale + (int64_t)b * mod_ld + d), sh = load8(shift + (int64_t)b * mod_ld + d);
+        const f32x8 xv = unpack8(v[it]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          o[e] = (xv[e] - mean) * rstd * (1.f + sc[e]) + sh[e];
+          mx = fmaxf(mx, fabsf(o[e]));
+        }
+        const unsigned lo = q8_pack4(o[0], o[1], o[2], o[3], qs), hi = q8_pack4(o[4], o[5], o[6], o[7], qs);
+        *reinterpret_cast<uint2*>(q8 + (int64_t)row * ldq + d) = uint2{lo, hi};
+        *reinterpret_cast<uint2*>(img + (8 * wave + r) * pitch + d) = uint2{lo, hi};
+      }
+    }
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  if (q_amax && threadIdx.x == 0) {
+    float a = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) a = fmaxf(a, red[w]);
+    const unsigned cur = __hip_atomic_load(reinterpret_cast<unsigned*>(q_amax), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__float_as_uint(a) > cur) atomicMax(reinterpret_cast<unsigned*>(q_amax), __float_as_uint(a));
+  }
+  // item = (column quad cq, row block rb): rows 16 rb .. + 15, columns 4 cq .. + 3; neighbouring lanes = the row blocks of one
+  // column quad, so that their 16-byte stores form one contiguous run of each column
+  constexpr int RB = NW / 2;
+  const int nq = D >> 2;
+  for (int idx = threadIdx.x; idx < RB * nq; idx += 64 * NW) {
+    const int cq = idx / RB, rb = idx - cq * RB;
+    const unsigned* src = reinterpret_cast<const unsigned*>(img + (16 * rb) * pitch) + cq;
+    unsigned w[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w[i] = src[i * (pitch >> 2)];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const unsigned sel = 0x0c0c0400u + (unsigned)e * 0x0101u;
+      uint4 o;
+      o.x = __builtin_amdgcn_perm(w[1], w[0], sel) | (__builtin_amdgcn_perm(w[3], w[2], sel) << 16);
+      o.y = __builtin_amdgcn_perm(w[5], w[4], sel) | (__builtin_amdgcn_perm(w[7], w[6], sel) << 16);
+      o.z = __builtin_amdgcn_perm(w[9], w[8], sel) | (__builtin_amdgcn_perm(w[11], w[10], sel) << 16);
+      o.w = __builtin_amdgcn_perm(w[13], w[12], sel) | (__builtin_amdgcn_perm(w[15], w[14], sel) << 16);
+      *reinterpret_cast<uint4*>(q8t + (int64_t)(4 * cq + e) * ldqt + row0 + 16 * rb) = o;
+    }
+  }
+}
+
 // One workgroup = ROWS consecutive rows of ONE sample (T_tok % ROWS == 0); the 4 waves split the rows, keep the
 // per-column partial sums for dshift/dscale/dgate in registers, fold them through LDS and issue one fp32 atomic
 // per column per workgroup.
@@ -477,6 +622,53 @@ __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ X, in
 }
 
 }  // namespace
+
+extern "C" int uwu_add_ln_modulate_fwd_q8(const void* x_in, const void* y, const float* gate, const float* shift,
+                                          const float* scale, int mod_ld, void* x_out, void* q8, int ldq, void* q8t, int ldqt,
+                                          const float* q_scale, float* q_amax, float* mean, float* rstd, int B, int T, int D,
+                                          float eps, void* stream) {
+  UWU_CHECK_ARG(x_in && q8 && q8t && q_scale && mean && rstd && shift && scale, "add_ln_modulate_fwd_q8: null pointer");
+  UWU_CHECK_ARG(B > 0 && T > 0 && D > 0 && D % 8 == 0 && D <= 1536, "add_ln_modulate_fwd_q8: D=%d unsupported", D);
+  UWU_CHECK_ARG(((int64_t)B * T) % 64 == 0, "add_ln_modulate_fwd_q8: B*T must be a multiple of 64");
+  UWU_CHECK_ARG((y == nullptr) || (gate && x_out), "add_ln_modulate_fwd_q8: y needs gate and x_out");
+  UWU_CHECK_ARG(mod_ld % 4 == 0, "add_ln_modulate_fwd_q8: mod_ld must be a multiple of 4");
+  UWU_CHECK_ARG((((uintptr_t)x_in | (uintptr_t)y | (uintptr_t)x_out | (uintptr_t)q8t) & 15) == 0 && ((uintptr_t)q8 & 7) == 0,
+                "add_ln_modulate_fwd_q8: misaligned tensor");
+  const int M = B * T;
+  UWU_CHECK_ARG(ldq >= D && ldq % 8 == 0 && ldqt >= M && ldqt % 16 == 0, "add_ln_modulate_fwd_q8: bad leading dimension");
+  hipStream_t st = (hipStream_t)stream;
+  // tile = 8 rows per wave: 8 waves (64-byte runs of the transposed image) while two such workgroups fit a CU's LDS, else 4
+  static UwuEnv nw_e("UWU_LN_Q8_NW");
+  int nw = (size_t)64 * (D + 8) * 2 <= 150 * 1024 ? 8 : 4;
+  if (nw_e.get().set && (nw_e.get().ival == 4 || nw_e.get().ival == 8)) nw = nw_e.get().ival;
+  UWU_CHECK_ARG(M % (8 * nw) == 0, "add_ln_modulate_fwd_q8: B*T must be a multiple of %d", 8 * nw);
+  const size_t lds = (size_t)8 * nw * (D + 8);
+  UwuProfScope prof(stream);
+#define Q8_LAUNCH(NIT, NW)                                                                                                 \
+  {                                                                                                                        \
+    static bool done = false;                                                                                              \
+    if (!done) {                                                                                                           \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(add_ln_mod_fwd_q8_kernel<NIT, NW>),                         \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 8 * NW * (1536 + 8));                          \
+      done = true;                                                                                                         \
+    }                                                                                                                      \
+    hipLaunchKernelGGL((add_ln_mod_fwd_q8_kernel<NIT, NW>), dim3(M / (8 * NW)), dim3(64 * NW), lds, st,                   \
+                       (const bf16_t*)x_in, (const bf16_t*)y, gate, shift, scale, mod_ld, (bf16_t*)x_out,                 \
+                       (unsigned char*)q8, ldq, (unsigned char*)q8t, ldqt, q_scale, q_amax, mean, rstd, M, T, D, eps);     \
+  }
+#define Q8_CASE(NIT)                \
+  case NIT:                         \
+    if (nw == 8) Q8_LAUNCH(NIT, 8)  \
+    else Q8_LAUNCH(NIT, 4)          \
+    break;
+  switch ((D + 511) / 512) { Q8_CASE(1) Q8_CASE(2) Q8_CASE(3) }
+#undef Q8_CASE
+#undef Q8_LAUNCH
+  const double md = (double)M * D;
+  prof.done(UWU_PROF_LN_FWD, 0, 8.0 * md, md * (2.0 * (1 + (y ? 2 : 0)) + 2.0));
+  UWU_LAUNCH_CHECK("add_ln_modulate_fwd_q8");
+  return UWU_OK;
+}
 
 extern "C" int uwu_add_ln_modulate_fwd(const void* x_in, const void* y, const float* gate, const float* shift,
                                        const float* scale, int mod_ld, void* x_out, void* h, float* mean, float* rstd,

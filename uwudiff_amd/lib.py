@@ -86,6 +86,7 @@ _SIGS = {
     "uwu_skinny_linear_dgrad": (c_int, [P, P, P, c_int, c_int, c_int, P]),
     "uwu_skinny_linear_wgrad": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     "uwu_add_ln_modulate_fwd": (c_int, [P, P, P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_float, c_int, c_int, P]),
+    "uwu_add_ln_modulate_fwd_q8": (c_int, [P, P, P, P, P, c_int, P, P, c_int, P, c_int, P, P, P, P, c_int, c_int, c_int, c_float, P]),
     "uwu_add_ln_modulate_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "uwu_attention_fwd": (c_int, [P, P, P, P, P] + [c_int] * 9 + [c_float, c_int, P]),
     "uwu_attention_bwd": (c_int, [P] * 10 + [c_int] * 9 + [c_float, c_int, P]),

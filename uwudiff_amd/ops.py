@@ -35,6 +35,19 @@ def add_ln_modulate_fwd(x_in, B, T, *, y=None, gate=None, shift=None, scale=None
     return x_out, h, mean, rstd
 
 
+def add_ln_modulate_fwd_q8(x_in, B, T, q_scale, *, shift, scale, mod_ld, y=None, gate=None, eps=1e-6, amax=None):
+    """fp8 mode: the LayerNorm output as e4m3 bytes, row-major [M, D] and transposed [D, M] (no bf16 h)."""
+    M, D = x_in.shape
+    x_out = torch.empty_like(x_in) if y is not None else x_in
+    q8 = torch.empty(M, D, device=x_in.device, dtype=torch.uint8)
+    q8t = torch.empty(D, M, device=x_in.device, dtype=torch.uint8)
+    mean = torch.empty(M, device=x_in.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    L.call("uwu_add_ln_modulate_fwd_q8", L.ptr(x_in), L.ptr(y), _p(gate), _p(shift), _p(scale), mod_ld, L.ptr(x_out), L.ptr(q8), D,
+           L.ptr(q8t), M, L.ptr(q_scale), L.ptr(amax), L.ptr(mean), L.ptr(rstd), B, T, D, eps, L.stream())
+    return x_out, q8, q8t, mean, rstd
+
+
 def add_ln_modulate_bwd(dh, x, mean, rstd, B, T, *, scale=None, dx_in=None, y=None, gate=None, mod_ld=0,
                         dshift=None, dscale=None, dgate=None, affine=False):
     M, D = x.shape
