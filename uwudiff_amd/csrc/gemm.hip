@@ -56,14 +56,6 @@ __device__ __forceinline__ uint4 lds_read128_asm(const char* p) {
   return uint4{v[0], v[1], v[2], v[3]};
 }
 
-// the same read with a compile-time byte offset (address arithmetic that costs no register)
-template <int OFF>
-__device__ __forceinline__ uint4 lds_read128_off(unsigned a) {
-  gu32x4 v;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
-  return uint4{v[0], v[1], v[2], v[3]};
-}
-
 // ---- staging: one 128-row x 128-byte operand tile per call, 256 threads ------------------------------
 template <typename T, bool TRANS>
 struct Stager {
@@ -195,7 +187,6 @@ struct GemmArgs {
   int cH, cW, cC, cHo, cWo, cS;  // input H x W x C (channels-last), output Ho x Wo, stride
   const void* zero;              // >= 16 zero bytes in device memory: the source of padded / out-of-range pixels
   // gemm_f8_kernel<EMIT>: the epilogue's result also leaves as fp8 bytes, row-major [M, N] and transposed [N, M]
-  int abl;  // timing-only ablations of gemm_wide_kernel (UWU_WIDE_ABL: 1 = no epilogue, 2 = no K loop); results are wrong
   void* q8;
   void* q8t;
   const float* q_scale;  // device float: q = sat(value * q_scale)
@@ -920,93 +911,81 @@ __global__ void __launch_bounds__(512, 2) gemm_big_kernel(const GemmArgs g) {
 // width, so A crosses L2 -> LDS once (128 flop per byte, as the 256x256 kernel, without its column padding).
 // Same structure as gemm_big_kernel: K-step 64 (128-byte rows), two stages of 72 KB, one workgroup per CU.
 // Images: A 192 rows | W 384 rows (TB = 0, swz) or 2 x 3 sub-images [32 k][128 n] (TB = 1, transposing reads).
-// PERS: one workgroup per CU walks the tiles of its XCD and the LDS-DMA pipeline never drains: the first K-step of tile t + 1 is
-// requested right after the last K-step of tile t, BEFORE the epilogue's stores, so in the in-order vmcnt sequence it is older than
-// they are and `vmcnt(NS)` (NS = stores per thread of one epilogue) lets the next tile start while the stores drain.  With
-// K = 384 a tile is 6 K-steps (6.6 us of MFMA at best) + 147 KB of output (6 us at a CU's share of HBM) + ~2 us of workgroup
-// launch and first-fetch latency: the non-persistent form paid the three one after the other.  Full tiles only (every thread
-// issues exactly NS stores).
-template <typename TC, int EPI, bool TB, bool PERS = false>
+template <typename TC, int EPI, bool TB>
 __global__ void __launch_bounds__(512, 2) gemm_wide_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef bf16_t T;
   constexpr int FI = 6, FJ = 6, BMR = 192, BNC = 384;
   constexpr int A_BYTES = BMR * ROW_BYTES, STAGE = (BMR + BNC) * ROW_BYTES;
-  constexpr int NS = FI * FJ / 2;  // 16-byte stores per thread of a one-output bf16 epilogue
-  static_assert(!PERS || (sizeof(TC) == 2 && (EPI == UWU_EPI_NONE || EPI == UWU_EPI_BIAS)), "persistent form: one bf16 output");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;
   const int fr = lane & 15, fq = lane >> 4;
   const int nblk = g.tiles_m * g.tiles_n;
-  // XCD-aware tile order as in gemm_kernel: XCD x owns a contiguous chunk of `cnt` tiles starting at `base`
-  const int xcd = blockIdx.x & 7, loc0 = blockIdx.x >> 3;
-  const int tq = nblk >> 3, trm = nblk & 7;
-  const int base = xcd < trm ? xcd * (tq + 1) : trm * (tq + 1) + (xcd - trm) * tq;
-  const int cnt = tq + (xcd < trm ? 1 : 0);
-  const int lstride = PERS ? (int)(gridDim.x >> 3) : cnt;  // (one tile per workgroup without PERS)
-  if (loc0 >= cnt) return;  // uniform per block
-  const int nk = g.abl == 2 ? 1 : g.K >> 6;
+  int tile;
+  {  // XCD-aware tile order as in gemm_kernel
+    const int bid = blockIdx.x, xcd = bid & 7, loc = bid >> 3;
+    const int q = nblk >> 3, rm = nblk & 7;
+    tile = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + loc;
+  }
+  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  const int m0 = tm * BMR, n0 = tn * BNC;
+  const int nk = g.K >> 6;
   const T* A = static_cast<const T*>(g.A);
   const T* B = static_cast<const T*>(g.B);
 
   // per-lane DMA sources; piece p = wave + 8 q is rows 8p .. 8p+7 of an image (lane: row lane>>3, 16-byte slot lane&7
   // receives the logical chunk the swizzle assigns to that slot).  Rows past the operand are clamped.
-  // (32-bit element offsets from A / B: the persistent form has no registers for nine 64-bit pointers; the host checks the sizes)
-  unsigned pa[3], pb[6];
-  auto setup = [&](int tile, int& m0, int& n0) {
-    const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
-    m0 = tm * BMR;
-    n0 = tn * BNC;
+  const T* pa[3];
+  const T* pb[6];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
+  for (int q = 0; q < 3; ++q) {
+    const int row = 8 * (wave + 8 * q) + (lane >> 3);
+    const int c = ((lane & 7) ^ (row >> 1) ^ (row >> 4)) & 7;
+    int grow = m0 + row;
+    if (grow >= g.M) grow = g.M - 1;
+    pa[q] = A + (int64_t)grow * g.lda + 8 * c;
+  }
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    if constexpr (!TB) {
       const int row = 8 * (wave + 8 * q) + (lane >> 3);
       const int c = ((lane & 7) ^ (row >> 1) ^ (row >> 4)) & 7;
-      int grow = m0 + row;
-      if (grow >= g.M) grow = g.M - 1;
-      pa[q] = (unsigned)grow * (unsigned)g.lda + 8u * c;
+      int grow = n0 + row;
+      if (grow >= g.N) grow = g.N - 1;
+      pb[q] = B + (int64_t)grow * g.ldb + 8 * c;
+    } else {  // q = 3 kh + nh: piece P = wave (k-rows 4P .. 4P+3) of sub-image (kh, nh)
+      const int kh = q / 3, nh = q - 3 * kh;
+      const int drow = lane >> 4;
+      const int dchunk = (lane & 15) ^ (((drow & 3) << 2) | (wave & 3));
+      int x = n0 + 128 * nh + 8 * dchunk;
+      if (x > g.N - 8) x = g.N - 8;
+      pb[q] = B + (int64_t)(32 * kh + 4 * wave + drow) * g.ldb + x;
     }
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-      if constexpr (!TB) {
-        const int row = 8 * (wave + 8 * q) + (lane >> 3);
-        const int c = ((lane & 7) ^ (row >> 1) ^ (row >> 4)) & 7;
-        int grow = n0 + row;
-        if (grow >= g.N) grow = g.N - 1;
-        pb[q] = (unsigned)grow * (unsigned)g.ldb + 8u * c;
-      } else {  // q = 3 kh + nh: piece P = wave (k-rows 4P .. 4P+3) of sub-image (kh, nh)
-        const int kh = q / 3, nh = q - 3 * kh;
-        const int drow = lane >> 4;
-        const int dchunk = (lane & 15) ^ (((drow & 3) << 2) | (wave & 3));
-        int x = n0 + 128 * nh + 8 * dchunk;
-        if (x > g.N - 8) x = g.N - 8;
-        pb[q] = (unsigned)(32 * kh + 4 * wave + drow) * (unsigned)g.ldb + x;
-      }
-    }
-  };
+  }
   // N = 384: this workgroup is the only reader of its A rows -> streaming (nt) DMA, so that the once-read activation does
   // not displace what the neighbouring launches re-read (per-kernel time unchanged, whole step +1.4 % on the same box)
   const bool a_once = g.tiles_n == 1;
-  auto issue = [&](int s, int stage) {  // K-step s of the tile pa / pb point at, into LDS stage `stage`
-    char* st = smem + stage * STAGE;
+  auto issue = [&](int s) {
+    char* st = smem + (s & 1) * STAGE;
     if (a_once) {
 #pragma unroll
       for (int q = 0; q < 3; ++q)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + pa[q] + 64 * s),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[q] + 64 * s),
                                          (__attribute__((address_space(3))) void*)(st + (wave + 8 * q) * 1024), 16, 0, 2);
     } else {
 #pragma unroll
       for (int q = 0; q < 3; ++q)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + pa[q] + 64 * s),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[q] + 64 * s),
                                          (__attribute__((address_space(3))) void*)(st + (wave + 8 * q) * 1024), 16, 0, 0);
     }
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
       if constexpr (!TB)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(B + pb[q] + 64 * s),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb[q] + 64 * s),
                                          (__attribute__((address_space(3))) void*)(st + A_BYTES + (wave + 8 * q) * 1024),
                                          16, 0, 0);
       else
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(B + pb[q] + (int64_t)(64 * s) * g.ldb),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb[q] + (int64_t)(64 * s) * g.ldb),
                                          (__attribute__((address_space(3))) void*)(st + A_BYTES + q * R_BSUB + wave * 1024),
                                          16, 0, 0);
     }
@@ -1022,98 +1001,55 @@ __global__ void __launch_bounds__(512, 2) gemm_wide_kernel(const GemmArgs g) {
       tb1[j] = A_BYTES + (col >> 7) * R_BSUB + tr_lane_base(lane, 1, (col & 127) >> 3);
     }
   }
-  // PERS: fragment addresses are formed at the read -- swz(96 w + 16 j + fr, 4 kk + fq) = (96 w + fr) * 128 + 2048 j +
-  // 16 * ((4 kk + fq) ^ (fr >> 1) ^ ((6 w + j) & 7)): one per-lane base per operand, a wave-uniform XOR constant per fragment
-  // and an immediate offset, instead of 36 precomputed address registers (which the persistent loop had no room for)
-  const int wm_s = __builtin_amdgcn_readfirstlane(wm), wn_s = __builtin_amdgcn_readfirstlane(wn);
-  const unsigned t_lane = (unsigned)((fq ^ (fr >> 1)) & 7) << 4;
-  const unsigned ra0 = smem_base + (unsigned)(96 * wm + fr) * ROW_BYTES + t_lane;
-  const unsigned rb0 = smem_base + (unsigned)A_BYTES + (unsigned)(96 * wn + fr) * ROW_BYTES + t_lane;
-  int m0, n0;
-  setup(base + loc0, m0, n0);
-  issue(0, 0);
-  int gs = 0;  // K-steps taken so far by this workgroup: stage = gs & 1
-  for (int loc = loc0; loc < cnt; loc += lstride) {
-    const int m0c = m0, n0c = n0;  // (setup() of the next tile overwrites m0 / n0 at this tile's last K-step)
-    f32x4 acc[FI][FJ];
+  f32x4 acc[FI][FJ];
 #pragma unroll
-    for (int i = 0; i < FI; ++i)
+  for (int i = 0; i < FI; ++i)
 #pragma unroll
-      for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < nk; ++s, ++gs) {
-      // stage gs landed (this wave's pieces).  First K-step of a later tile: its DMA is older than the previous epilogue's
-      // NS stores, which may stay in flight
-      if (PERS && s == 0 && loc != loc0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();  // ... everybody's; everybody is done reading the other stage
-      if (s + 1 < nk) issue(s + 1, (gs + 1) & 1);
-      const char* la = smem + (gs & 1) * STAGE;
-      const char* lb = la + A_BYTES;
-      const unsigned ras = ra0 + (unsigned)((gs & 1) * STAGE), rbs = rb0 + (unsigned)((gs & 1) * STAGE);
+    for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  issue(0);
+  for (int s = 0; s < nk; ++s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stage s landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();                     // ... everybody's; everybody is done reading stage s - 1
+    if (s + 1 < nk) issue(s + 1);
+    const char* la = smem + (s & 1) * STAGE;
+    const char* lb = la + A_BYTES;
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        uint4 bf[FJ], af[FI];
-        auto xk = [&](int w, int f) { return (unsigned)((((6 * w + f) & 7) ^ (4 * kk)) << 4); };  // wave-uniform
-        if constexpr (!TB && PERS) {
-          bf[0] = lds_read128_off<0>(rbs ^ xk(wn_s, 0));
-          bf[1] = lds_read128_off<2048>(rbs ^ xk(wn_s, 1));
-          bf[2] = lds_read128_off<4096>(rbs ^ xk(wn_s, 2));
-          bf[3] = lds_read128_off<6144>(rbs ^ xk(wn_s, 3));
-          bf[4] = lds_read128_off<8192>(rbs ^ xk(wn_s, 4));
-          bf[5] = lds_read128_off<10240>(rbs ^ xk(wn_s, 5));
-        } else if constexpr (!TB) {
+    for (int kk = 0; kk < 2; ++kk) {
+      uint4 bf[FJ], af[FI];
+      if constexpr (!TB) {
 #pragma unroll
-          for (int j = 0; j < FJ; ++j) bf[j] = lds_read128_asm(lb + swz(96 * wn + 16 * j + fr, 4 * kk + fq));
-        } else {
-          const unsigned sb = smem_base + (unsigned)((gs & 1) * STAGE + kk * 3 * R_BSUB);
+        for (int j = 0; j < FJ; ++j) bf[j] = lds_read128_asm(lb + swz(96 * wn + 16 * j + fr, 4 * kk + fq));
+      } else {
+        const unsigned sb = smem_base + (unsigned)((s & 1) * STAGE + kk * 3 * R_BSUB);
 #pragma unroll
-          for (int j = 0; j < FJ; ++j) {
-            const uint2 lo = t_read_tr<0>(sb + tb0[j]);
-            const uint2 hi = t_read_tr<0>(sb + tb1[j]);
-            bf[j] = uint4{lo.x, lo.y, hi.x, hi.y};
-          }
+        for (int j = 0; j < FJ; ++j) {
+          const uint2 lo = t_read_tr<0>(sb + tb0[j]);
+          const uint2 hi = t_read_tr<0>(sb + tb1[j]);
+          bf[j] = uint4{lo.x, lo.y, hi.x, hi.y};
         }
-        if constexpr (PERS) {
-          af[0] = lds_read128_off<0>(ras ^ xk(wm_s, 0));
-          af[1] = lds_read128_off<2048>(ras ^ xk(wm_s, 1));
-          af[2] = lds_read128_off<4096>(ras ^ xk(wm_s, 2));
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          af[3] = lds_read128_off<6144>(ras ^ xk(wm_s, 3));
-          af[4] = lds_read128_off<8192>(ras ^ xk(wm_s, 4));
-          af[5] = lds_read128_off<10240>(ras ^ xk(wm_s, 5));
-        } else {
-#pragma unroll
-          for (int i = 0; i < 3; ++i) af[i] = lds_read128_asm(la + swz(96 * wm + 16 * i + fr, 4 * kk + fq));
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-          for (int i = 3; i < FI; ++i) af[i] = lds_read128_asm(la + swz(96 * wm + 16 * i + fr, 4 * kk + fq));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-          for (int j = 0; j < FJ; ++j) mma_frag<T>(bf[j], af[i], acc[i][j]);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 3; i < FI; ++i)
-#pragma unroll
-          for (int j = 0; j < FJ; ++j) mma_frag<T>(bf[j], af[i], acc[i][j]);
       }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) af[i] = lds_read128_asm(la + swz(96 * wm + 16 * i + fr, 4 * kk + fq));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 3; i < FI; ++i) af[i] = lds_read128_asm(la + swz(96 * wm + 16 * i + fr, 4 * kk + fq));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) mma_frag<T>(bf[j], af[i], acc[i][j]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 3; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) mma_frag<T>(bf[j], af[i], acc[i][j]);
     }
-    // first K-step of the next tile, into the stage that step nk - 2 read (everybody passed the barrier of step nk - 1 since):
-    // requested BEFORE this tile's stores (setup() here and not inside the K loop: beside the live fragments it spilled)
-    if (g.abl == 1) continue;
-    int m0e = m0c, n0e = n0c;
-    if constexpr (PERS) asm volatile("" : "+s"(m0e), "+s"(n0e));  // (keeps the epilogue's address arithmetic below the K loop: hoisted above it, it spilled)
-    if (PERS && loc + lstride < cnt) {
-      setup(base + loc + lstride, m0, n0);
-      issue(0, gs & 1);
-    }
-    EpiPre<T, FI, FJ> pre;
-    epi_prefetch<T, FI, FJ, EPI>(pre, g, m0e + wm * 96, n0e + wn * 96, fr, fq);
-    epilogue_tile<T, TC, FI, FJ, EPI>(acc, pre, g, m0e + wm * 96, n0e + wn * 96, fr, fq, nullptr, wm, wn & 1);
   }
+  EpiPre<T, FI, FJ> pre;
+  epi_prefetch<T, FI, FJ, EPI>(pre, g, m0 + wm * 96, n0 + wn * 96, fr, fq);
+  epilogue_tile<T, TC, FI, FJ, EPI>(acc, pre, g, m0 + wm * 96, n0 + wn * 96, fr, fq, nullptr, wm, wn & 1);
 }
 
 // ---- 64x128 tile for small token counts (a 128x128 grid that would leave most CUs idle) ---------------------------
@@ -2209,51 +2145,19 @@ static bool use_m64(const GemmArgs& g, bool tb) {
   const int thr = thr_e.get().set ? thr_e.ival : 256;
   return tiles < thr && g.M > 64;
 }
-// compute units of the current device (0 if the query fails: callers then take the non-persistent kernels)
-static int uwu_num_cus() {
-  static int n = -1;
-  if (n < 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
-  }
-  return n;
-}
 template <typename TC, int EPI, bool TB>
 int launch_wide(GemmArgs g, hipStream_t st) {
+  auto kern = gemm_wide_kernel<TC, EPI, TB>;
   constexpr int LDS = 2 * (192 + 384) * ROW_BYTES;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_done = true;
+  }
   g.tiles_m = (g.M + 191) / 192;
   g.tiles_n = g.N / 384;
-  const int nblk = g.tiles_m * g.tiles_n;
   UwuProfScope prof(st);
-  // persistent form (one bf16 output, full tiles, more than one round of the chip): OPT-IN with UWU_GEMM_WIDE_PERS=1 -- bit-identical
-  // but 5-30 % slower than one workgroup per tile as built (tools/bench_wide_pers.py): at 256 registers the
-  // two-level loop spills, and scratch loads share the in-order vmcnt with the LDS-DMA
-  static UwuEnv pers_e("UWU_GEMM_WIDE_PERS"), abl_e("UWU_WIDE_ABL");
-  g.abl = abl_e.get().set ? abl_e.get().ival : 0;
-  bool launched = false;
-  if constexpr (sizeof(TC) == 2 && (EPI == UWU_EPI_NONE || EPI == UWU_EPI_BIAS)) {
-    const int cus = uwu_num_cus();
-    if (pers_e.get().is('1') && g.wide && g.M % 192 == 0 && cus > 0 && nblk > cus && cus % 8 == 0) {  // (g.wide: 16-byte stores)
-      auto kern = gemm_wide_kernel<TC, EPI, TB, true>;
-      static bool attr_done = false;
-      if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_done = true;
-      }
-      hipLaunchKernelGGL(kern, dim3(cus), dim3(512), LDS, st, g);
-      launched = true;
-    }
-  }
-  if (!launched) {
-    auto kern = gemm_wide_kernel<TC, EPI, TB, false>;
-    static bool attr_done = false;
-    if (!attr_done) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      attr_done = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), LDS, st, g);
-  }
+  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(512), LDS, st, g);
   prof.done(gemm_tag(g, TB, false), 0, 2.0 * g.M * g.N * g.K, gemm_bytes(g, 2, sizeof(TC)));
   UWU_LAUNCH_CHECK("gemm_wide");
   return UWU_OK;
