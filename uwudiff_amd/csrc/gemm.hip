@@ -56,14 +56,6 @@ __device__ __forceinline__ uint4 lds_read128_asm(const char* p) {
   return uint4{v[0], v[1], v[2], v[3]};
 }
 
-// the same read with a compile-time byte offset (address arithmetic that costs no register)
-template <int OFF>
-__device__ __forceinline__ uint4 lds_read128_off(unsigned a) {
-  gu32x4 v;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
-  return uint4{v[0], v[1], v[2], v[3]};
-}
-
 // ---- staging: one 128-row x 128-byte operand tile per call, 256 threads ------------------------------
 template <typename T, bool TRANS>
 struct Stager {
@@ -179,15 +171,6 @@ __device__ __forceinline__ void mma_frag(const uint4& a, const uint4& b, f32x4& 
 #pragma unroll
     for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[e], c, 0, 0, 0);
   }
-}
-
-// accumulate IN PLACE in AGPRs: with 240 accumulator registers the allocator otherwise writes each MFMA's result to a fresh
-// tuple and copies the lot back at the loop's back edge (300 v_accvgpr moves per K-step against 120 MFMAs)
-typedef float af32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void mma_agpr(const uint4& a, const uint4& b, f32x4& c) {
-  typedef unsigned mu32x4 __attribute__((ext_vector_type(4)));
-  const mu32x4 av = {a.x, a.y, a.z, a.w}, bv = {b.x, b.y, b.z, b.w};
-  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(av), "v"(bv));
 }
 
 struct GemmArgs {
@@ -1067,197 +1050,6 @@ __global__ void __launch_bounds__(512, 2) gemm_wide_kernel(const GemmArgs g) {
   EpiPre<T, FI, FJ> pre;
   epi_prefetch<T, FI, FJ, EPI>(pre, g, m0 + wm * 96, n0 + wn * 96, fr, fq);
   epilogue_tile<T, TC, FI, FJ, EPI>(acc, pre, g, m0 + wm * 96, n0 + wn * 96, fr, fq, nullptr, wm, wn & 1);
-}
-
-// ---- the same 192x384 tile with FOUR waves (2 x 2 of 96 x 192: FI = 6, FJ = 12), one wave per SIMD ------------------------
-// The 8-wave form above is bound inside its K loop by the LDS pipe as much as by the matrix pipe: its 96 x 96 wave tile reads
-// (96 + 96) x 64 B of fragments per 36 MFMAs, 192 KB per K-step and CU against 0.96 us of MFMA (1.7 us per
-// K-step).  A wave that owns 96 x 192 of the tile reads (96 + 192) x 64 B per 72 MFMAs -- 3/4 of the LDS traffic per MFMA,
-// and with one wave per SIMD the whole 512-register file is the wave's: 288 accumulator registers, BOTH k-halves' fragments
-// resident (the reads of the second half run under the MFMAs of the first), room to spare.  What the second wave of a SIMD
-// used to hide must be interleaved by hand: the 18 LDS-DMA requests of the next stage go out one per 8 MFMAs.
-template <typename TC, int EPI, bool TB>
-__global__ void __launch_bounds__(256, 1) gemm_wide4_kernel(const GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  typedef bf16_t T;
-  constexpr int FI = 5, FJ = 12, BMR = 16 * FI * 2, BNC = 384, NDMA = FI + 12;  // 160 x 384 tile: 240 accumulator registers (AGPRs)
-  constexpr int A_BYTES = BMR * ROW_BYTES, STAGE = (BMR + BNC) * ROW_BYTES;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int fr = lane & 15, fq = lane >> 4;
-  const int nblk = g.tiles_m * g.tiles_n;
-  int tile;
-  {  // XCD-aware tile order as in gemm_kernel
-    const int bid = blockIdx.x, xcd = bid & 7, loc = bid >> 3;
-    const int q = nblk >> 3, rm = nblk & 7;
-    tile = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + loc;
-  }
-  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
-  const int m0 = tm * BMR, n0 = tn * BNC;
-  const int nk = g.K >> 6;
-  const T* A = static_cast<const T*>(g.A);
-  const T* B = static_cast<const T*>(g.B);
-
-  // per-lane DMA sources: 18 pieces of 1 KB per wave and stage.  A / W (TB = 0): piece p = wave + 4 q = rows 8p .. 8p+7 of
-  // the image (lane: row lane>>3, 16-byte slot lane&7 receives the chunk the swizzle assigns to it); rows past the operand
-  // are clamped.  TB = 1: sub-image (kh, nh) = [32 k][128 n], piece P = wave + 4 ph = its k-rows 4P .. 4P+3.
-  // (32-bit element offsets: the host takes this kernel only for operands below 2^31 elements)
-  unsigned pa[FI], pb[12];
-#pragma unroll
-  for (int q = 0; q < FI; ++q) {
-    const int row = 8 * (wave + 4 * q) + (lane >> 3);
-    const int c = ((lane & 7) ^ (row >> 1) ^ (row >> 4)) & 7;
-    int grow = m0 + row;
-    if (grow >= g.M) grow = g.M - 1;
-    pa[q] = (unsigned)grow * (unsigned)g.lda + 8u * c;
-  }
-#pragma unroll
-  for (int q = 0; q < 12; ++q) {
-    if constexpr (!TB) {
-      const int row = 8 * (wave + 4 * q) + (lane >> 3);
-      const int c = ((lane & 7) ^ (row >> 1) ^ (row >> 4)) & 7;
-      int grow = n0 + row;
-      if (grow >= g.N) grow = g.N - 1;
-      pb[q] = (unsigned)grow * (unsigned)g.ldb + 8u * c;
-    } else {
-      const int sub = q >> 1, ph = q & 1, kh = sub / 3, nh = sub - 3 * kh;
-      const int P = wave + 4 * ph;
-      const int drow = lane >> 4;
-      const int dchunk = (lane & 15) ^ (((drow & 3) << 2) | (P & 3));
-      int x = n0 + 128 * nh + 8 * dchunk;
-      if (x > g.N - 8) x = g.N - 8;
-      pb[q] = (unsigned)(32 * kh + 4 * P + drow) * (unsigned)g.ldb + x;
-    }
-  }
-  const bool a_once = g.tiles_n == 1;  // (N = 384: the only reader of its A rows -> streaming DMA, as in the 8-wave form)
-  // request piece `idx` (0..FI-1: A, FI..: B) of K-step s
-  auto dma = [&](int idx, int s) {
-    char* st = smem + (s & 1) * STAGE;
-    if (idx < FI) {
-      const int q = idx;
-      if (a_once)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + pa[q] + 64 * s),
-                                         (__attribute__((address_space(3))) void*)(st + (wave + 4 * q) * 1024), 16, 0, 2);
-      else
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + pa[q] + 64 * s),
-                                         (__attribute__((address_space(3))) void*)(st + (wave + 4 * q) * 1024), 16, 0, 0);
-    } else {
-      const int q = idx - FI;
-      if constexpr (!TB) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(B + pb[q] + 64 * s),
-                                         (__attribute__((address_space(3))) void*)(st + A_BYTES + (wave + 4 * q) * 1024), 16, 0, 0);
-      } else {
-        const int sub = q >> 1, ph = q & 1;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(B + pb[q] + (int64_t)(64 * s) * g.ldb),
-                                         (__attribute__((address_space(3))) void*)(st + A_BYTES + sub * R_BSUB + (wave + 4 * ph) * 1024),
-                                         16, 0, 0);
-      }
-    }
-  };
-  const unsigned smem_base = (unsigned)(size_t)((const __attribute__((address_space(3))) char*)smem);
-  // TB = 1: fragment j starts at column 192 wn + 16 j: sub-image (col >> 7), first 8-column chunk (col & 127) >> 3
-  unsigned tb0[FJ], tb1[FJ];
-  if constexpr (TB) {
-#pragma unroll
-    for (int j = 0; j < FJ; ++j) {
-      const int col = 192 * wn + 16 * j;
-      tb0[j] = A_BYTES + (col >> 7) * R_BSUB + tr_lane_base(lane, 0, (col & 127) >> 3);
-      tb1[j] = A_BYTES + (col >> 7) * R_BSUB + tr_lane_base(lane, 1, (col & 127) >> 3);
-    }
-  }
-  f32x4 acc[FI][FJ];
-#pragma unroll
-  for (int i = 0; i < FI; ++i)
-#pragma unroll
-    for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // fragment read r (0..11: B fragment r, 12..17: A fragment r - 12) of k-half kk of stage st.  Addresses are formed at the
-  // read: swz(R + 16 f + fr, 4 kk + fq) = (R + fr) * 128 + 2048 f + 16 * ((4 kk + fq) ^ (fr >> 1) ^ ((R / 16 + f) & 7)) for a
-  // wave-uniform R that is a multiple of 16 -- one per-lane base per operand, a wave-uniform XOR constant per fragment and an
-  // immediate offset, instead of 36 address registers
-  uint4 fb[2][FJ], fa[2][FI];
-  const int wm_s = __builtin_amdgcn_readfirstlane(wm), wn_s = __builtin_amdgcn_readfirstlane(wn);
-  const unsigned t_lane = (unsigned)((fq ^ (fr >> 1)) & 7) << 4;
-  const unsigned ra0 = smem_base + (unsigned)(16 * FI * wm + fr) * ROW_BYTES + t_lane;
-  const unsigned rb0 = smem_base + (unsigned)A_BYTES + (unsigned)(192 * wn + fr) * ROW_BYTES + t_lane;
-#define W4_RD(DST, BASE, W6, F) DST = lds_read128_off<2048 * (F)>((BASE) ^ (unsigned)(((((W6) + (F)) & 7) ^ (4 * kk)) << 4))
-  auto rd = [&](int r, int kk, int st) {
-    const unsigned so = (unsigned)(st * STAGE);
-    if (r >= FJ) {
-      const unsigned ba = ra0 + so;
-      switch (r - FJ) {
-        case 0: W4_RD(fa[kk][0], ba, FI * wm_s, 0); break;
-        case 1: W4_RD(fa[kk][1], ba, FI * wm_s, 1); break;
-        case 2: W4_RD(fa[kk][2], ba, FI * wm_s, 2); break;
-        case 3: W4_RD(fa[kk][3], ba, FI * wm_s, 3); break;
-        case 4: W4_RD(fa[kk][4], ba, FI * wm_s, 4); break;
-        default: if constexpr (FI > 5) { W4_RD(fa[kk][FI - 1], ba, FI * wm_s, 5); } break;
-      }
-    } else if constexpr (!TB) {
-      const unsigned bb = rb0 + so;
-      switch (r) {
-        case 0: W4_RD(fb[kk][0], bb, 12 * wn_s, 0); break;
-        case 1: W4_RD(fb[kk][1], bb, 12 * wn_s, 1); break;
-        case 2: W4_RD(fb[kk][2], bb, 12 * wn_s, 2); break;
-        case 3: W4_RD(fb[kk][3], bb, 12 * wn_s, 3); break;
-        case 4: W4_RD(fb[kk][4], bb, 12 * wn_s, 4); break;
-        case 5: W4_RD(fb[kk][5], bb, 12 * wn_s, 5); break;
-        case 6: W4_RD(fb[kk][6], bb, 12 * wn_s, 6); break;
-        case 7: W4_RD(fb[kk][7], bb, 12 * wn_s, 7); break;
-        case 8: W4_RD(fb[kk][8], bb, 12 * wn_s, 8); break;
-        case 9: W4_RD(fb[kk][9], bb, 12 * wn_s, 9); break;
-        case 10: W4_RD(fb[kk][10], bb, 12 * wn_s, 10); break;
-        default: W4_RD(fb[kk][11], bb, 12 * wn_s, 11); break;
-      }
-    } else {
-      const unsigned sb = smem_base + so + (unsigned)(kk * 3 * R_BSUB);
-      const uint2 lo = t_read_tr<0>(sb + tb0[r]);
-      const uint2 hi = t_read_tr<0>(sb + tb1[r]);
-      fb[kk][r] = uint4{lo.x, lo.y, hi.x, hi.y};
-    }
-  };
-#undef W4_RD
-
-#pragma unroll
-  for (int idx = 0; idx < NDMA; ++idx) dma(idx, 0);
-  for (int s = 0; s < nk; ++s) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stage s landed (this wave's pieces)
-    __builtin_amdgcn_s_barrier();                     // ... everybody's; everybody is done reading stage s - 1
-    const int st = s & 1;
-    const bool more = s + 1 < nk;
-#pragma unroll
-    for (int r = 0; r < FJ + FI; ++r) rd(r, 0, st);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    // k-half 0: 72 MFMAs; under them the 18 fragment reads of k-half 1 and the first 9 DMA requests of stage s + 1
-#pragma unroll
-    for (int i = 0; i < FI; ++i) {
-#pragma unroll
-      for (int j = 0; j < FJ; ++j) {
-        const int m = i * FJ + j;
-        if (m % 3 == 0 && m / 3 < FJ + FI) rd(m / 3, 1, st);
-        if (m % 6 == 4 && m / 6 < NDMA / 2 && more) dma(m / 6, s + 1);
-        mma_agpr(fb[0][j], fa[0][i], acc[i][j]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < FI; ++i) {
-#pragma unroll
-      for (int j = 0; j < FJ; ++j) {
-        const int m = i * FJ + j;
-        if (m % 6 == 4 && NDMA / 2 + m / 6 < NDMA && more) dma(NDMA / 2 + m / 6, s + 1);
-        mma_agpr(fb[1][j], fa[1][i], acc[i][j]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // (the asm MFMAs' results are read by VALU below: the hazard the compiler cannot see)
-  EpiPre<T, FI, FJ> pre;
-  epi_prefetch<T, FI, FJ, EPI>(pre, g, m0 + wm * 16 * FI, n0 + wn * 192, fr, fq);
-  epilogue_tile<T, TC, FI, FJ, EPI>(acc, pre, g, m0 + wm * 16 * FI, n0 + wn * 192, fr, fq, nullptr, wm, wn & 1);
 }
 
 // ---- 64x128 tile for small token counts (a 128x128 grid that would leave most CUs idle) ---------------------------
@@ -2355,20 +2147,17 @@ static bool use_m64(const GemmArgs& g, bool tb) {
 }
 template <typename TC, int EPI, bool TB>
 int launch_wide(GemmArgs g, hipStream_t st) {
-  static UwuEnv w4("UWU_GEMM_WIDE4");  // "1": the four-wave form (one wave per SIMD, 96 x 192 wave tiles)
-  auto kern = w4.get().is('1') ? gemm_wide4_kernel<TC, EPI, TB> : gemm_wide_kernel<TC, EPI, TB>;
-  const int threads = w4.get().is('1') ? 256 : 512;
+  auto kern = gemm_wide_kernel<TC, EPI, TB>;
   constexpr int LDS = 2 * (192 + 384) * ROW_BYTES;
   static bool attr_done = false;
-  if (!attr_done) {  // (both forms: the switch can flip inside a process)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<TC, EPI, TB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide4_kernel<TC, EPI, TB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_done = true;
   }
-  g.tiles_m = w4.get().is('1') ? (g.M + 159) / 160 : (g.M + 191) / 192;  // (the four-wave form: 160-row tiles)
+  g.tiles_m = (g.M + 191) / 192;
   g.tiles_n = g.N / 384;
   UwuProfScope prof(st);
-  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(threads), LDS, st, g);
+  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(512), LDS, st, g);
   prof.done(gemm_tag(g, TB, false), 0, 2.0 * g.M * g.N * g.K, gemm_bytes(g, 2, sizeof(TC)));
   UWU_LAUNCH_CHECK("gemm_wide");
   return UWU_OK;
