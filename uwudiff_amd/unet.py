@@ -144,6 +144,9 @@ def _wgrad_blocks(M, N, K):
     return 768 if tiles >= 16 else 256
 
 
+_SKINNY = os.environ.get("UWU_UNET_SKINNY", "1") != "0"  # A/B switch: the generic fp32 GEMM for the few-row Linears
+
+
 class _LinearFn(torch.autograd.Function):
     """y = x W^T (+ b); W is a [N, K] view of the flat parameters, grads accumulate into the flat grad buffer."""
 
@@ -153,19 +156,32 @@ class _LinearFn(torch.autograd.Function):
         # (sinusoid features, text context); needs_input_grad[0] then stays False and the dgrad GEMM is skipped
         W = P.w32(wname) if fp32 else P.w(wname)
         b = P.w32(bname) if bname else None
-        y = ops.gemm(x, W, bias=b, epilogue=L.EPI_BIAS if b is not None else L.EPI_NONE)
+        # fp32 Linears on a handful of rows (time / text-time embedding MLPs, the resblocks' time_emb_proj: M = batch): the
+        # matrix-vector kernels of the conditioning path (csrc/skinny.hip) instead of a 128-row MFMA tile with 12 live rows
+        skinny = (fp32 and x.dtype == torch.float32 and x.is_contiguous() and x.shape[0] <= 64 and _SKINNY
+                  and ops.skinny_linear_ok(x.shape[0], W.shape[0], x.shape[1]))
+        if skinny:
+            y = ops.skinny_linear_fwd(x, W, b)
+        else:
+            y = ops.gemm(x, W, bias=b, epilogue=L.EPI_BIAS if b is not None else L.EPI_NONE)
         ctx.save_for_backward(x)
-        ctx.meta = (P, wname, bname, fp32)
+        ctx.meta = (P, wname, bname, fp32, skinny)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
-        P, wname, bname, fp32 = ctx.meta
+        P, wname, bname, fp32, skinny = ctx.meta
         dy = dy.contiguous()
         W = P.w32(wname) if fp32 else P.w(wname)
         M, K = x.shape
         N = W.shape[0]
+        if skinny and dy.dtype == torch.float32:
+            dx = None
+            if ctx.needs_input_grad[0]:  # (the matrix-vector input gradient covers K <= 512: the DiT widths, not 1280)
+                dx = ops.skinny_linear_dgrad(dy, W) if K <= 512 else ops.gemm(dy, W, trans_b=True)
+            P.on_side(lambda: ops.skinny_linear_wgrad(dy, x, P.g(wname), P.g(bname) if bname else None), dy, x)
+            return dx, None, None, None, None, None
         dx = ops.gemm(dy, W, trans_b=True) if ctx.needs_input_grad[0] else None
         # dW += dy^T x and db += colsum(dy) in one launch where the streaming kernel takes the shape
         P.on_side(lambda: ops.gemm_wgrad_shared(dy, x, P.g(wname), blocks=_wgrad_blocks(M, N, K),
