@@ -102,6 +102,21 @@ def test_c1_loss_curve_overlay():
     assert dev < 2e-3, dev                   # HIP fp32 curve tracks it step by step
 
 
+@pytest.mark.parametrize("dtype,tol", [("bf16", 2e-3)])
+def test_c2_dit_s2_loss_curve_overlay(dtype, tol):
+    """The same overlay on the headline denoiser (C2: DiT-S/2, full depth, 4x32x32 latents, batch 16, eps objective, AdamW):
+    the HIP path's per-step loss against the fp32 CPU oracle trained from the same state_dict with the same injected
+    (noise, t) stream.  A per-layer error of a few percent -- which the 3e-2 / 6e-2 one-pass tolerances of the bf16 parity tests
+    would let through -- moves this curve: the 60-step curves in profiles/r01_loss_curve_c2_dit_s2_*.csv deviate by 7.6e-4
+    (bf16) and 3.5e-7 (fp32) at most; 8 bf16 steps here (the CPU oracle takes 4 s per step; fp32 mode has its own 1e-3
+    one-pass parity tests)."""
+    from tests.loss_curve_overlay import main_dit
+
+    rows, dev = main_dit(steps=8, dtype=dtype)
+    assert rows[-1][1] < rows[0][1]
+    assert dev < tol, dev
+
+
 def test_checkpoint_resume_reproduces_the_run(tmp_path):
     """Save after 3 steps (Lightning checkpoint layout: `state_dict` with `unet.*` keys, `optimizer_states`,
     `lr_schedulers`, `global_step`), resume in fresh objects, and take the same steps 4-5 as the uninterrupted run;
