@@ -1,5 +1,5 @@
-"""Weight-gradient launches of the SDXL-shape UNet's Linears at 4x128x128 latents, batch 6 (K = tokens), us per launch.
-Usage: [UWU_TR_SPLIT=n] python tools/probe_wgrad_unet.py"""
+"""Weight-gradient launches of the SDXL-shape UNet's Linears at 4x128x128 latents (K = tokens), us per launch.
+Usage: [UWU_TR_SPLIT=n] python tools/probe_wgrad_unet.py [batch]      (default batch 12: the bench's)"""
 import os
 import sys
 
@@ -10,8 +10,10 @@ from uwudiff_amd import ops  # noqa: E402
 from tools.bench_kernels import timeit  # noqa: E402
 
 tot = 0.0
-for (m, n, k, cnt) in [(1280, 1280, 6144, 180), (3840, 1280, 6144, 60), (10240, 1280, 6144, 60), (1280, 5120, 6144, 60),
-                       (640, 640, 24576, 30), (1920, 640, 24576, 10), (5120, 640, 24576, 10), (640, 2560, 24576, 10)]:
+Bt = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+T32, T64 = Bt * 1024, Bt * 4096
+for (m, n, k, cnt) in [(1280, 1280, T32, 180), (3840, 1280, T32, 60), (10240, 1280, T32, 60), (1280, 5120, T32, 60),
+                       (640, 640, T64, 30), (1920, 640, T64, 10), (5120, 640, T64, 10), (640, 2560, T64, 10)]:
     a = torch.randn(k, m, device="cuda").bfloat16()
     b = torch.randn(k, n, device="cuda").bfloat16()
     out = torch.zeros(m, n, device="cuda")
