@@ -195,11 +195,11 @@ def test_gemm_fp8_emit_matches_quantised_result(epi, M, N, K):
     torch.testing.assert_close(amax.cpu(), val.abs().max().reshape(1), rtol=2e-2, atol=0)
 
 
-@pytest.mark.parametrize("D,B,T,with_y", [(1152, 3, 256, True), (384, 2, 96, False), (768, 1, 320, True)])
+@pytest.mark.parametrize("D,B,T,with_y", [(1152, 3, 256, True), (384, 2, 96, False), (768, 1, 320, True), (1536, 2, 160, True)])
 def test_layernorm_emits_fp8_images(D, B, T, with_y):
     """fp8 mode: LayerNorm + modulate writing the next GEMM's e4m3 operand (row-major + transposed) instead of bf16 h.
     Residual stream and statistics bit-equal to the plain kernel's; the bytes = RNE quantisation of the fp32 output (within one
-    e4m3 step where a rounding flips); the transposed image is the exact transpose; amax recorded.  Rows straddle samples."""
+    e4m3 step where a rounding flips); the transposed image is the exact transpose; amax recorded.  Rows straddle samples; D = 1536 takes the 32-row tiles (two 64-row tiles would not fit a CU's LDS)."""
     from uwudiff_amd import ops
 
     torch.manual_seed(21)
