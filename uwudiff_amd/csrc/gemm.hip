@@ -2198,6 +2198,52 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
   }
 }
 
+// The same sum with the slices divided among four lanes of threads: a workgroup takes 64 float4 of the output per pass, thread
+// (zl, cl) adds slices zl, zl + 4, .. of column group cl on two accumulators (loads of 8 slices in flight), the four partial sums
+// meet in LDS.  With one thread per output float4 a [384 x 384] gradient in 128 slices was 36 864 threads walking 128 dependent
+// adds each on 144 of the 256 CUs.
+__global__ void __launch_bounds__(256) splitk_reduce4_kernel(const float* __restrict__ part, float* __restrict__ C,
+                                                             int M, int N, int ldc, int split) {
+  __shared__ f32x4 red[4][64];
+  const int zl = threadIdx.x >> 6, cl = threadIdx.x & 63;
+  const int64_t slice = (int64_t)M * N;
+  for (int64_t base = (int64_t)blockIdx.x * 256; base < slice; base += (int64_t)gridDim.x * 256) {
+    const int64_t idx = base + 4 * cl;
+    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+    if (idx < slice) {
+      int z = zl;
+      for (; z + 4 < split; z += 8) {
+        v0 = v0 + load4(part + (int64_t)z * slice + idx);
+        v1 = v1 + load4(part + (int64_t)(z + 4) * slice + idx);
+      }
+      if (z < split) v0 = v0 + load4(part + (int64_t)z * slice + idx);
+    }
+    red[zl][cl] = v0 + v1;
+    __syncthreads();
+    if (zl == 0 && idx < slice) {
+      const f32x4 v = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+      const int m = (int)(idx / N), n = (int)(idx - (int64_t)m * N);
+      float* c = C + (int64_t)m * ldc + n;
+      store4(c, load4(c) + v);
+    }
+    __syncthreads();
+  }
+}
+// launches the reduce (UWU_SPLITK_REDUCE4=0: the one-thread-per-float4 form)
+static void launch_splitk_reduce(const float* part, float* C, int M, int N, int ldc, int split, hipStream_t st) {
+  static UwuEnv r4("UWU_SPLITK_REDUCE4");
+  const int64_t quads = (int64_t)M * N / 4;
+  if (!r4.get().is('0') && split >= 8) {
+    int rg = (int)((quads + 63) / 64);
+    if (rg > 8192) rg = 8192;
+    hipLaunchKernelGGL(splitk_reduce4_kernel, dim3(rg), dim3(256), 0, st, part, C, M, N, ldc, split);
+    return;
+  }
+  int rg = (int)((quads + 255) / 256);
+  if (rg > 4096) rg = 4096;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, st, part, C, M, N, ldc, split);
+}
+
 // Number of K slices for the streaming weight-gradient kernel: a multiple of 8 (one group of slices per XCD), as
 // many groups as fit the XCD's 64 workgroup slots (32 CUs x 2) in one round.
 // Outputs with >= 64 tiles of a reduction of a few thousand rows: fewer slices, the XCDs divided between slices and tiles
@@ -2263,11 +2309,7 @@ int launch_tr(GemmArgs g, void* scratch, size_t scratch_bytes, hipStream_t st) {
   } else if (part) {
     g.C2 = scratch;
     hipLaunchKernelGGL((gemm_tr_kernel<FI, FJ, true, CONVW>), dim3(grid), dim3(256), T_NST * T_STAGE, st, g);
-    const int64_t quads = (int64_t)g.M * g.N / 4;
-    int rg = (int)((quads + 255) / 256);
-    if (rg > 4096) rg = 4096;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, st, static_cast<const float*>(scratch),
-                       static_cast<float*>(g.C), g.M, g.N, g.ldc, split);
+    launch_splitk_reduce(static_cast<const float*>(scratch), static_cast<float*>(g.C), g.M, g.N, g.ldc, split, st);
   } else {
     hipLaunchKernelGGL((gemm_tr_kernel<FI, FJ, false, CONVW>), dim3(grid), dim3(256), T_NST * T_STAGE, st, g);
   }
@@ -2322,11 +2364,7 @@ int launch_trw(GemmArgs g, void* scratch, hipStream_t st) {
   const int grid = 8 * tiles * ((split + 7) / 8);
   UwuProfScope prof(st);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), NST * W_STAGE, st, g);
-  const int64_t quads = (int64_t)g.M * g.N / 4;
-  int rg = (int)((quads + 255) / 256);
-  if (rg > 4096) rg = 4096;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, st, static_cast<const float*>(scratch),
-                     static_cast<float*>(g.C), g.M, g.N, g.ldc, split);
+  launch_splitk_reduce(static_cast<const float*>(scratch), static_cast<float*>(g.C), g.M, g.N, g.ldc, split, st);
   prof.done(UWU_PROF_GEMM_WGRAD, 0, 2.0 * g.M * g.N * g.K, ((double)g.M * g.K + (double)g.N * g.K) * 2 + (double)g.M * g.N * 4);
   UWU_LAUNCH_CHECK("gemm_trw");
   return UWU_OK;
@@ -2525,11 +2563,7 @@ int launch_f8_part(GemmArgs g, const float* sa, const float* sb, void* scratch, 
   const int grid = 8 * tiles * ((split + 7) / 8);
   UwuProfScope prof(st);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, st, g, sa, sb);
-  const int64_t quads = (int64_t)g.M * g.N / 4;
-  int rg = (int)((quads + 255) / 256);
-  if (rg > 4096) rg = 4096;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rg), dim3(256), 0, st, static_cast<const float*>(scratch),
-                     static_cast<float*>(g.C), g.M, g.N, g.ldc, split);
+  launch_splitk_reduce(static_cast<const float*>(scratch), static_cast<float*>(g.C), g.M, g.N, g.ldc, split, st);
   prof.done(UWU_PROF_GEMM_WGRAD, 0, 2.0 * g.M * g.N * g.K, ((double)g.M * g.K + (double)g.N * g.K) + (double)g.M * g.N * 4);
   UWU_LAUNCH_CHECK("gemm_f8(split-K)");
   return UWU_OK;
