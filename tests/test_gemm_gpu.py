@@ -501,3 +501,72 @@ def test_gemm_as_exact_integers_all_epilogues(N):
     ops.gemm(a16, b16, aux=aux, epilogue=L.EPI_DGELU, out=d)
     fac = torch.where(aux == 0, 0.5, torch.where(aux > 0, 1.0, 0.0)).float()
     torch.testing.assert_close(d.float(), ref * fac, rtol=0, atol=1e-20)
+
+
+# ---- 8-phase 256 x 256 kernel (gemm_p8.hip): K >= 512 Linears of DiT-B/2, DiT-XL/2, the UNet ---------------------------------
+# UWU_GEMM_P8=1 forces it on any shape it can run, =0 keeps the older kernels.  Its MFMA sequence per output element is the
+# 128x128 kernel's (K steps of 64 in order, two 32-deep halves each), so every epilogue must agree BIT FOR BIT on random
+# operands; exact-integer operands pin the half-tile ring (a stale or early read of a slot shows as a wrong integer).
+P8_SHAPES = [(4096, 1024, 768), (2048, 768, 3072), (1000, 520, 128), (777, 1160, 960), (512, 256, 192), (300, 264, 1088)]
+
+
+def _p8_both(monkeypatch, fn):
+    monkeypatch.setenv("UWU_GEMM_P8", "0")
+    ref = fn()
+    monkeypatch.setenv("UWU_GEMM_P8", "1")
+    return ref, fn()
+
+
+@pytest.mark.parametrize("M,N,K", P8_SHAPES)
+def test_gemm_p8_exact_integers(M, N, K, monkeypatch):
+    from uwudiff_amd import ops
+
+    monkeypatch.setenv("UWU_GEMM_P8", "1")
+    a, b = _operands(M, N, K, False, False, torch.bfloat16, ints=True, seed=51)
+    for _ in range(3):  # repeated launches: the ring's ordering must hold under different timings
+        c = ops.gemm(a, b)
+        assert torch.equal(c.float(), (a.float() @ b.float().t()).bfloat16().float())
+    dy, w = _operands(M, N, K, False, True, torch.bfloat16, ints=True, seed=52)
+    for _ in range(3):
+        c = ops.gemm(dy, w, trans_b=True)
+        assert torch.equal(c.float(), (dy.float() @ w.float()).bfloat16().float())
+
+
+@pytest.mark.parametrize("M,N,K", P8_SHAPES)
+def test_gemm_p8_matches_older_kernels(M, N, K, monkeypatch):
+    from uwudiff_amd import lib as L
+    from uwudiff_amd import ops
+
+    a, b = _operands(M, N, K, False, False, torch.bfloat16, ints=False, seed=53)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(54)).cuda()
+    for kw in ({}, dict(bias=bias, epilogue=L.EPI_BIAS)):
+        ref, got = _p8_both(monkeypatch, lambda: ops.gemm(a, b, **kw))
+        assert torch.equal(ref, got)
+    (u0, f0), (u1, f1) = _p8_both(monkeypatch, lambda: ops.gemm(a, b, bias=bias, epilogue=L.EPI_BIAS_GELU))
+    assert torch.equal(u0, u1) and torch.equal(f0, f1)
+    dy, w = _operands(M, N, K, False, True, torch.bfloat16, ints=False, seed=55)
+    ref, got = _p8_both(monkeypatch, lambda: ops.gemm(dy, w, trans_b=True))
+    assert torch.equal(ref, got)
+    u = (torch.randn(M, N, generator=torch.Generator().manual_seed(56)) * 1.5).bfloat16().cuda()
+
+    def run():
+        cs = torch.zeros(N, device="cuda")
+        out = ops.gemm(dy, w, trans_b=True, aux=u, epilogue=L.EPI_DGELU, out2=cs)
+        return (out[0] if isinstance(out, tuple) else out), cs
+
+    (d0, s0), (d1, s1) = _p8_both(monkeypatch, run)
+    assert torch.equal(d0, d1)
+    torch.testing.assert_close(s0, s1, rtol=1e-3, atol=0.5)  # fp32 atomics: order differs
+    ref, got = _p8_both(monkeypatch, lambda: ops.gemm(dy, w, trans_b=True, aux=u, epilogue=L.EPI_DGELU))
+    assert torch.equal(ref, got)
+
+
+def test_gemm_p8_bench_shape_exact(monkeypatch):
+    """DiT-B/2 fc1 at the secondary bench's launch shape (3072 tiles = 12 rounds of CUs), exact integers, default dispatch."""
+    from uwudiff_amd import ops
+
+    M, N, K = 65536, 3072, 768
+    a, b = _operands(M, N, K, False, False, torch.bfloat16, ints=True, seed=57)
+    want = (a.float() @ b.float().t()).bfloat16()
+    for _ in range(2):
+        assert torch.equal(ops.gemm(a, b), want)
