@@ -2327,7 +2327,7 @@ extern "C" int uwu_gemm(const void* A, const void* B, void* C, void* C2, const f
   } else {
     UWU_CHECK_ARG(c_dtype == UWU_F32 && ldc >= N, "gemm: ACCUM needs fp32 C");
   }
-  GemmArgs g;
+  GemmArgs g{};
   g.A = A; g.B = B; g.C = C; g.C2 = C2; g.bias = bias; g.aux = aux;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux; g.epi = epilogue;
   g.tiles_m = (M + BM - 1) / BM;
@@ -2335,6 +2335,10 @@ extern "C" int uwu_gemm(const void* A, const void* B, void* C, void* C2, const f
   // 16-byte epilogue stores need 8-column granularity and 16-byte aligned rows
   g.wide = (!acc && c_dtype == UWU_BF16 && N % 8 == 0 && ldc % 8 == 0 && ((uintptr_t)C & 15) == 0 &&
             (C2 == nullptr || epilogue == UWU_EPI_DGELU || ((uintptr_t)C2 & 15) == 0)) ? 1 : 0;
+  {
+    static UwuEnv ntc("UWU_GEMM_NT_C");
+    g.nt_c = ntc.get().set ? ntc.ival : 0;
+  }
   g.aux16 = (epilogue == UWU_EPI_DGELU && dtype == UWU_BF16 && N % 8 == 0 && ldaux % 8 == 0 && ((uintptr_t)aux & 15) == 0) ? 1 : 0;
   {
     static UwuEnv a16("UWU_GEMM_AUX16");  // "0": the 8-byte aux loads (A/B comparisons)

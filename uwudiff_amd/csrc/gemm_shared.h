@@ -33,6 +33,8 @@ struct GemmArgs {
   const float* q_scale;  // device float: q = sat(value * q_scale)
   float* q_amax;         // optional: atomic max |value|
   int ldq, ldqt;
+  int nt_c;  // bit 0 / 1: bf16 wide stores of C / C2 are streaming (nontemporal) stores: UWU_GEMM_NT_C (experiments)
+  int p8_cont;  // gemm_p8_kernel: continuous mode allowed (UWU_P8_CONT=0: every tile drains; A/B comparisons)
 };
 
 namespace {
@@ -380,8 +382,8 @@ __device__ __forceinline__ void epilogue_tile(f32x4 (&acc)[FI][FJ], EpiPre<T, FI
           };
           // the pre-activation of a GELU Linear is only read again in the backward pass: streaming store, so that
           // it does not push the activation (read next by fc2) out of the caches
-          exchange_store(C, v[2 * jp], v[2 * jp + 1], epi == UWU_EPI_BIAS_GELU);
-          if (two) exchange_store(C2, sec[2 * jp], sec[2 * jp + 1]);
+          exchange_store(C, v[2 * jp], v[2 * jp + 1], epi == UWU_EPI_BIAS_GELU || (g.nt_c & 1));
+          if (two) exchange_store(C2, sec[2 * jp], sec[2 * jp + 1], (g.nt_c & 2) != 0);
         }
       }
     } else {
