@@ -570,3 +570,4 @@ def test_gemm_p8_bench_shape_exact(monkeypatch):
     want = (a.float() @ b.float().t()).bfloat16()
     for _ in range(2):
         assert torch.equal(ops.gemm(a, b), want)
+
