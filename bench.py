@@ -248,7 +248,7 @@ def main():
         i = step_no[0]
         off = (i * b) % (pool_n - b + 1)
         x, c = pool[off:off + b], pooled[off:off + b]
-        model.flat.grad.zero_()
+        # (the flat gradient buffer was zeroed by the AdamW kernel of the previous step: FusedAdamW.step(zero_grad=True))
         if unet:
             loss, _ = loss_fn(x, model, encoder_hidden_states=ctx[:b], added_cond_kwargs={"text_embeds": c, "time_ids": time_ids[:b]})
         else:
@@ -259,9 +259,9 @@ def main():
         if args.clip > 0:
             sy.wait_all()
             clip = opt.grad_norm_clip(args.clip, pre_scale=sy.pre_scale)
-            opt.step(clip=clip, pre_scale=sy.pre_scale)
+            opt.step(clip=clip, pre_scale=sy.pre_scale, zero_grad=True)
         else:
-            opt.step(pre_scale=sy.pre_scale, chunks=chunks, before_chunk=sy.wait_chunk)
+            opt.step(pre_scale=sy.pre_scale, chunks=chunks, before_chunk=sy.wait_chunk, zero_grad=True)
         step_no[0] += 1
         return loss
 

@@ -83,6 +83,20 @@ int uwu_qsample(const float* x, const float* noise, const float* coef, int B, in
 int uwu_qsample_norm(const float* x, const float* noise, const float* coef, int B, int64_t n, float vae_mean,
                      float vae_std, float* x_norm, float* noisy, void* stream);
 
+/* In-kernel draws of the training objective (diffusion.py:68-70 `torch.randint(0, N, (B,))`, :75 `torch.randn_like(x)`;
+ * rectified_flow.py:37 `torch.rand(B)`): Philox4x32-10, counter = offset + element group, key = seed (no device state).  The
+ * host mirror reserves the offset ranges in the reference's order of draws (noise, then timesteps / u01) from torch's CUDA
+ * generator.  uwu_philox_raw: n_counters x 4 raw words (parity with oracle/philox.py); uwu_philox_normal: n N(0,1) floats, 4 per
+ * counter (Box-Muller); uwu_draw_timesteps: t[b] = (word (b % 4) of counter b / 4) * n_train >> 32; uwu_draw_u01: the same word
+ * as ((r >> 8) + 1/2) / 2^24.  uwu_qsample_draw = uwu_qsample / uwu_qsample_norm with the noise drawn inside (element group i of
+ * the [B, n] tensor = counter offset + i): writes noise, noisy and (use_norm) x_norm in one pass. */
+int uwu_philox_raw(uint32_t* out, int64_t n_counters, uint64_t seed, uint64_t offset, void* stream);
+int uwu_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+int uwu_draw_timesteps(int64_t* timesteps, int n_train, int B, uint64_t seed, uint64_t offset, void* stream);
+int uwu_draw_u01(float* u01, int B, uint64_t seed, uint64_t offset, void* stream);
+int uwu_qsample_draw(const float* x, const float* coef, int B, int64_t n, int use_norm, float vae_mean, float vae_std,
+                     float* x_norm, float* noise, float* noisy, uint64_t seed, uint64_t offset, void* stream);
+
 /* Conditioning front-end, text_encoders.py:196-262: place one text encoder's hidden states src [B,S,F] (fp32 / bf16),
  * times its attention mask [B,S] (int64, may be NULL: zero_for_padding off or no mask), into the zero-filled context
  * out [B,S_total,F_total] (fp32) at sequence offset s_off (its concat bucket) and feature offset f_off (its place
@@ -145,9 +159,9 @@ int uwu_grad_sqnorm_clip(const float* g, int64_t n, float pre_scale, float max_n
 /* torch.optim.AdamW single-tensor semantics (trainer.py:52-74, demo_training_latent.yaml:30-39) on flat
  * buffers; g_eff = g * pre_scale * clip[1] (clip may be NULL).  Also refreshes the bf16 shadow
  * (may be NULL).  step is the 1-based step count. */
-int uwu_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
+int uwu_adamw_step(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
                    float beta1, float beta2, float eps, float weight_decay, int step, float pre_scale,
-                   const float* clip, void* stream);
+                   const float* clip, int zero_grad, void* stream);
 
 int uwu_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int uwu_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);

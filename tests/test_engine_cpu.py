@@ -186,6 +186,46 @@ def test_checkpoint_resume_continues_epoch_count_and_topk(tmp_path):
         assert (sorted(os.listdir(dk)) if os.path.exists(dk) else []) == want
 
 
+class _DM3(_DM):
+    """three batches per epoch"""
+
+    def train_dataloader(self):
+        return [(torch.full((4,), self.scale), [""], [], {}, {}) for _ in range(3)]
+
+
+def test_partial_epoch_is_not_counted_and_resume_skips_the_right_batches(tmp_path):
+    """max_steps inside an epoch must not fire the epoch-end hooks nor count the epoch; the checkpoint stores how far
+    into its epoch it was written; max_steps ON an epoch boundary must not run an empty extra epoch."""
+    from uwudiff_amd.engine import Fitter, ModelCheckpoint
+
+    # (1) max_steps = 4 with 3 batches per epoch: epoch 0 complete, epoch 1 cut after one batch
+    d = tmp_path / "p"
+    cb = ModelCheckpoint(dirpath=str(d), every_n_epochs=1, save_top_k=-1, save_last=True)
+    fit = Fitter(accelerator="cpu", callbacks=[cb], max_steps=4, max_epochs=100)
+    fit.fit(_FakeTrainer(torch.optim.SGD), _DM3(1.0))
+    assert fit.global_step == 4 and fit.current_epoch == 1 and fit.batches_in_epoch == 1
+    assert sorted(os.listdir(d)) == ["epoch=0-step=3.ckpt", "last.ckpt"]  # one epoch-end file: the partial epoch wrote none
+    last = torch.load(d / "last.ckpt", weights_only=True)
+    assert last["epoch"] == 1 and last["global_step"] == 4 and last["batches_in_epoch"] == 1
+    # resume to max_steps = 8: skips ONE batch of epoch 1, finishes it at step 6 (epoch-end file named epoch=1), runs two of epoch 2
+    cb2 = ModelCheckpoint(dirpath=str(d), every_n_epochs=1, save_top_k=-1)
+    fit2 = Fitter(accelerator="cpu", callbacks=[cb2], max_steps=8, max_epochs=100)
+    fit2.fit(_FakeTrainer(torch.optim.SGD), _DM3(1.0), ckpt_path=str(d / "last.ckpt"))
+    assert fit2.global_step == 8 and fit2.current_epoch == 2 and fit2.batches_in_epoch == 2
+    assert "epoch=1-step=6.ckpt" in os.listdir(d) and "epoch=2-step=8.ckpt" not in os.listdir(d)
+    # (2) max_steps = 6 = two whole epochs: both epoch-end hooks fire once, no third (empty) epoch, no duplicate file
+    d2 = tmp_path / "q"
+    cb3 = ModelCheckpoint(dirpath=str(d2), every_n_epochs=1, save_top_k=2)
+    fit3 = Fitter(accelerator="cpu", callbacks=[cb3], max_steps=6, max_epochs=100)
+    fit3.fit(_FakeTrainer(torch.optim.SGD), _DM3(1.0))
+    assert fit3.global_step == 6 and fit3.current_epoch == 2
+    assert sorted(os.listdir(d2)) == ["epoch=0-step=3.ckpt", "epoch=1-step=6.ckpt"]
+    # (3) a checkpoint written at an epoch's last batch resumes into the NEXT epoch
+    fit4 = Fitter(accelerator="cpu", callbacks=[], max_steps=7, max_epochs=100)
+    fit4.fit(_FakeTrainer(torch.optim.SGD), _DM3(1.0), ckpt_path=str(d2 / "epoch=1-step=6.ckpt"))
+    assert fit4.global_step == 7 and fit4.current_epoch == 2 and fit4.batches_in_epoch == 1
+
+
 def test_launcher_passes_resume_checkpoint_through():
     src = open(os.path.join(ROOT, "test_scripts", "test_train.py")).read()
     assert "ckpt_path=ckpt_path" in src and "not supported" not in src

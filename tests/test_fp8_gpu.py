@@ -275,3 +275,69 @@ def test_dit_xl2_width_fp8_close_to_oracle(scaling):
     bad = {n: _rel(model.grad_view(n), og[n].grad) for n, _ in model.named_tensors()
            if _rel(model.grad_view(n), og[n].grad) >= 0.12}
     assert not bad, bad
+
+
+def _fp8_pair(scaling):
+    from uwudiff_amd.dit import DiT, DiTConfig
+
+    torch.manual_seed(5)
+    a = DiT(DiTConfig(compute_dtype="fp8", fp8_scaling=scaling, **XL2_CUT), init="random").cuda()
+    b = DiT(DiTConfig(compute_dtype="fp8", fp8_scaling=scaling, **XL2_CUT), init="random").cuda()
+    b.load_state_dict(a.state_dict())
+    return a, b
+
+
+def _fp8_step(model, x, t, pooled, dout):
+    model.flat.grad = torch.zeros_like(model.flat.data)
+    y = model(x, t, added_cond_kwargs={"text_embeds": pooled})[0]
+    y.backward(dout)
+    torch.cuda.synchronize()
+    return y.detach().clone(), model.flat.grad.clone()
+
+
+@pytest.mark.parametrize("scaling", ["delayed", "jit"])
+def test_dit_fp8_block_recomputation_equals_plain_backward(scaling):
+    """block recomputation in fp8 mode.  The rerun of a block inside the backward reuses the fp8 scratch
+    images (x8 / dy8 / dy8t, the buffers the emitting GEMMs hand du through), re-records amax and -- just-in-time scaling --
+    rewrites scale[role]; correctness rests on launch order only.  Three steps (just-in-time, delayed, delayed + emitting
+    epilogues) of two models with identical weights, one plain, one with enable_gradient_checkpointing(): outputs bit-equal,
+    gradients equal up to the order of their fp32 atomic adds -- the tolerance of the bf16 / fp32 recomputation test."""
+    plain, ckpt = _fp8_pair(scaling)
+    ckpt.enable_gradient_checkpointing()
+    g = torch.Generator().manual_seed(7)
+    B = 8
+    for step in range(3):
+        x = torch.randn(B, 4, 32, 32, generator=g).cuda()
+        t = torch.randint(0, 1000, (B,), generator=g).float().cuda()
+        pooled = torch.randn(B, 1280, generator=g).cuda()
+        dout = (torch.randn(B, 4, 32, 32, generator=g) / 1024).cuda()
+        y0, g0 = _fp8_step(plain, x, t, pooled, dout)
+        y1, g1 = _fp8_step(ckpt, x, t, pooled, dout)
+        assert plain._f8_mode == ckpt._f8_mode == (2 if scaling == "delayed" and step > 0 else 1)
+        assert torch.equal(y0, y1), (step, (y0 - y1).abs().max().item())
+        l2 = ((g1 - g0).norm() / g0.norm()).item()
+        mx = ((g1 - g0).abs().max() / g0.abs().max()).item()
+        assert l2 < 1e-4 and mx < 1e-3, (step, l2, mx)
+    assert ckpt._ws.numel() < plain._ws.numel()
+
+
+def test_dit_fp8_emit_switch_compares_two_paths(monkeypatch):
+    """UWU_F8_EMIT is re-read after a change inside a process (UwuEnv), so this A/B really runs the emitting epilogues
+    against the two-pass quantisation: same losses / gradients within the fp8 tolerance of the emitting GEMM's own test (the
+    pre-activation's rounding may flip in < 1 % of the elements), and NOT the same bits (two code paths)."""
+    a, b = _fp8_pair("delayed")
+    g = torch.Generator().manual_seed(9)
+    B = 8
+    differs = False
+    for step in range(3):
+        x = torch.randn(B, 4, 32, 32, generator=g).cuda()
+        t = torch.randint(0, 1000, (B,), generator=g).float().cuda()
+        pooled = torch.randn(B, 1280, generator=g).cuda()
+        dout = (torch.randn(B, 4, 32, 32, generator=g) / 1024).cuda()
+        monkeypatch.setenv("UWU_F8_EMIT", "1")
+        y0, g0 = _fp8_step(a, x, t, pooled, dout)
+        monkeypatch.setenv("UWU_F8_EMIT", "0")
+        y1, g1 = _fp8_step(b, x, t, pooled, dout)
+        assert _rel(y1, y0) < 2e-2 and _rel(g1, g0) < 5e-2, (step, _rel(y1, y0), _rel(g1, g0))
+        differs = differs or not torch.equal(g0, g1)
+    assert differs  # steps 1 and 2 run delayed scaling: the switch selects different kernels there

@@ -6,7 +6,7 @@ import os
 import pytest
 import torch
 
-from tests.conftest import ROOT
+from tests.conftest import GOLDEN, ROOT
 
 
 def test_instantiate_dialects():
@@ -187,3 +187,43 @@ def test_plain_clip_text_model_gets_layer_norm_of_the_chosen_layer():
         want = model.final_layer_norm(hidden[-2]) if sd1 else last
         torch.testing.assert_close(normed, want)
         assert not torch.allclose(model.final_layer_norm(hidden[-2]), last)
+
+
+def test_duwu_utils_import_surface_and_list_helpers(tmp_path):
+    """the reference's ``duwu.utils`` helpers exist again; the list helpers are pinned by fixtures the reference's own
+    functions produced (oracle/make_golden_utils.py -> tests/golden/utils_helpers.json)."""
+    import json
+    import logging
+
+    import torch
+
+    import duwu.utils as U
+
+    for name in ("exists", "uniq", "default", "zero_module", "random_choice", "count_params", "remove_none",
+                 "balance_sharding_index", "balance_sharding", "balance_sharding_max_size", "truncate_or_pad_to_length",
+                 "repeat_last", "cycling", "uniform_expansion", "get_duwu_logger", "setup_duwu_logger", "get_images_recursively",
+                 "instantiate_any", "instantiate_class", "get_obj_from_str"):
+        assert callable(getattr(U, name)), name
+    g = json.load(open(os.path.join(GOLDEN, "utils_helpers.json")))
+    for total, shards, want in g["balance_sharding_index"]:
+        assert [list(t) for t in U.balance_sharding_index(total, shards)] == want
+    for xs, tgt, mode, want in g["truncate_or_pad_to_length"]:
+        assert U.truncate_or_pad_to_length(list(xs), tgt, mode) == want, (xs, tgt, mode)
+    for xs, ms, want in g["balance_sharding_max_size"]:
+        assert [list(x) for x in U.balance_sharding_max_size(xs, ms)] == want
+    for xs, want in g["uniq"]:
+        assert list(U.uniq(xs)) == want
+    for xs, want in g["remove_none"]:
+        assert U.remove_none(xs) == want
+    assert U.exists(0) and not U.exists(None) and U.default(None, lambda: 5) == 5 and U.default(0, 7) == 0
+    lin = torch.nn.Linear(3, 2)
+    assert U.count_params(lin) == 8 and U.zero_module(lin) is lin and float(lin.weight.abs().sum()) == 0.0
+    assert U.random_choice(torch.arange(12).view(6, 2), 4).shape == (4, 2)
+    assert U.get_duwu_logger() is logging.getLogger("duwu")
+    (tmp_path / "a").mkdir()
+    for f in ("a/x.PNG", "a/y.jpeg", "z.txt", "w.gif"):
+        (tmp_path / f).write_bytes(b"0")
+    got = [os.path.relpath(p, tmp_path) for p in U.get_images_recursively(str(tmp_path))]
+    assert got == ["a/x.PNG", "a/y.jpeg", "w.gif"]
+    with pytest.raises(ValueError):
+        U.get_images_recursively(str(tmp_path / "missing"))

@@ -188,7 +188,8 @@ def test_adamw_and_clip_vs_torch():
         gd = g.cuda()
         L.call("uwu_grad_sqnorm_clip", L.ptr(gd), n, 1.0, 1.0, L.ptr(part), L.ptr(out), L.stream())
         L.call("uwu_adamw_step", L.ptr(p), L.ptr(gd), L.ptr(m), L.ptr(v), L.ptr(pbf), n, 1e-3, 0.9, 0.999, 1e-8,
-               0.01, step, 1.0, L.ptr(out), L.stream())
+               0.01, step, 1.0, L.ptr(out), int(step == 5), L.stream())
+        assert (gd == 0).all().item() == (step == 5)  # zero_grad: the consumed gradient is left zeroed by the same kernel
         close(out[0].sqrt(), tn, rtol=1e-5, atol=0)
         close(p, ref.data, rtol=1e-5, atol=1e-6)
     close(pbf, ref.data.bfloat16().float(), rtol=8e-3, atol=1e-6)
@@ -218,3 +219,84 @@ def test_nn_weighted_rf_loss_vs_reference_golden(name):
     close(out.grad, d["dloss_dout"], rtol=6e-4, atol=1e-7)
     for k, p in (("grad_a", lp.a), ("grad_b", lp.b), ("grad_c", lp.c)):
         close(p.grad, d[k], rtol=2e-3, atol=1e-5)
+
+
+# ---- in-kernel draws: Philox4x32-10 (objective.hip) against its CPU restatement (oracle/philox.py, pinned by the Random123
+# known-answer vectors in tests/test_oracle_loss.py) ------------------------------------------------------------------------
+@pytest.mark.parametrize("seed,offset", [(0, 0), (1215, 0), (0xDEADBEEFCAFEF00D, 12345), (7, (1 << 32) - 3), (3, (1 << 40) + 5)])
+def test_philox_words_bit_exact(seed, offset):
+    from oracle import philox as OP
+    from uwudiff_amd import lib as L
+
+    n = 4099
+    out = torch.empty(n, 4, device="cuda", dtype=torch.int32)
+    L.call("uwu_philox_raw", L.ptr(out), n, seed, offset, L.stream())
+    want = OP.philox(n, seed, offset).astype("uint32")
+    assert (out.cpu().numpy().view("uint32") == want).all()
+
+
+def test_philox_draws_match_oracle_and_moments():
+    from oracle import philox as OP
+    from uwudiff_amd import lib as L
+
+    seed, off = 1215, 64
+    n = 1 << 22
+    z = torch.empty(n, device="cuda")
+    L.call("uwu_philox_normal", L.ptr(z), n, seed, off, L.stream())
+    zo = torch.from_numpy(OP.normal(1 << 16, seed, off))
+    # the kernel uses the fast log / sincos: a few 1e-6 of absolute error on |z| <= 6
+    assert (z[:1 << 16].cpu() - zo).abs().max().item() < 2e-4
+    zc = z.double()
+    m, v = zc.mean().item(), zc.var().item()
+    skew, kurt = ((zc - m) ** 3).mean().item() / v ** 1.5, ((zc - m) ** 4).mean().item() / v ** 2
+    assert abs(m) < 3e-3 and abs(v - 1) < 5e-3 and abs(skew) < 1e-2 and abs(kurt - 3) < 3e-2, (m, v, skew, kurt)
+    B = 100_001
+    t = torch.empty(B, device="cuda", dtype=torch.int64)
+    L.call("uwu_draw_timesteps", L.ptr(t), 1000, B, seed, off, L.stream())
+    assert torch.equal(t.cpu(), torch.from_numpy(OP.timesteps(B, 1000, seed, off)))
+    cnt = torch.bincount(t.cpu(), minlength=1000).double()
+    chi2 = ((cnt - B / 1000) ** 2 / (B / 1000)).sum().item()
+    assert t.min().item() == 0 and t.max().item() == 999 and 800 < chi2 < 1200, chi2  # 999 degrees of freedom: 999 +- 3 sigma = 134
+    u = torch.empty(B, device="cuda")
+    L.call("uwu_draw_u01", L.ptr(u), B, seed, off, L.stream())
+    assert torch.equal(u.cpu(), torch.from_numpy(OP.uniform(B, seed, off)))
+    assert 0 < u.min().item() and u.max().item() < 1 and abs(u.mean().item() - 0.5) < 5e-3
+
+
+def test_diffusion_loss_draws_are_the_librarys_and_follow_manual_seed():
+    """Without injection: noise by the q-sample kernel's Philox draw, timesteps by the library's draw kernel, both from counters
+    reserved on torch's CUDA generator in the reference's order (noise first, diffusion.py:75-76); torch.manual_seed reproduces
+    the step, the generator's offset moves on, and the forward process equals the oracle's composition of the same draws."""
+    from oracle import philox as OP
+    from uwudiff_amd.objective import DiffusionLoss, RectifiedFlowLoss
+
+    B = 6
+    x = torch.randn(B, 4, 8, 8, device="cuda")
+    net = lambda n, t, **kw: (n * 0.5,)  # noqa: E731
+
+    def run(seed):
+        torch.manual_seed(seed)
+        mod = DiffusionLoss(_sched())
+        gen = torch.cuda.default_generators[torch.cuda.current_device()]
+        off0 = gen.get_offset()
+        loss, aux = mod(x, net)
+        return loss.item(), aux, off0, gen.get_offset()
+
+    l0, a0, off0, off1 = run(5)
+    l1, a1, _, _ = run(5)
+    l2, a2, _, _ = run(6)
+    assert l0 == l1 and torch.equal(a0.timesteps, a1.timesteps) and torch.equal(a0.noisy_latent, a1.noisy_latent)
+    assert l0 != l2 and not torch.equal(a0.noisy_latent, a2.noisy_latent)
+    n_noise = x.numel() // 4
+    assert off1 - off0 == n_noise + 4  # noise counters (already a multiple of 4), then ceil(B / 4) = 2 -> granule 4 for t
+    noise = torch.from_numpy(OP.normal(x.numel(), 5, off0)).view_as(x)
+    t = torch.from_numpy(OP.timesteps(B, 1000, 5, off0 + n_noise))
+    assert torch.equal(a0.timesteps.cpu(), t)
+    sig = _sched().sigmas[999 - t].view(B, 1, 1, 1)
+    want = (x.cpu() + noise * sig) / (sig * sig + 1).sqrt()
+    close(a0.noisy_latent, want, rtol=1e-5, atol=2e-4)
+    # rectified flow: u01 from the library's draw, rescale_noise takes the noise tensor at once
+    torch.manual_seed(9)
+    rf = RectifiedFlowLoss(scheduler=_sched(), rescale_noise=True)
+    loss, aux = rf(x, net)
+    assert torch.isfinite(loss) and 0 <= aux.timesteps.min().item() and aux.timesteps.max().item() <= 999

@@ -118,3 +118,20 @@ def test_analytic_grad_matches_autograd():
             o = OL.diffusion_loss(s, x, n, t, lambda a, b: out, prediction_type=p, target_type=tt)
             (g,) = torch.autograd.grad(o.loss, out)
             close(o.dloss_dout, g, rtol=1e-4, atol=1e-7)
+
+
+def test_philox4x32_10_known_answers():
+    """oracle/philox.py against the known-answer vectors of the Random123 distribution (kat_vectors, philox4x32 10 rounds):
+    the all-zero, all-ones and pi-digits counters / keys."""
+    from oracle import philox as OP
+
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for c, k, want in kat:
+        assert [int(v) for v in OP.philox4x32_10_words([c], [k])[0]] == list(want)
+    z = OP.normal(1 << 16, 1215, 0)
+    assert abs(float(z.mean())) < 2e-2 and abs(float(z.std()) - 1) < 2e-2
+    t = OP.timesteps(20000, 1000, 3, 8)
+    assert t.min() == 0 and t.max() == 999

@@ -117,6 +117,32 @@ def test_c2_dit_s2_loss_curve_overlay(dtype, tol):
     assert dev < tol, dev
 
 
+@pytest.mark.parametrize("preset,dtype,steps,tol", [("DiT-B/2", "bf16", 6, 1e-3), ("DiT-XL/2", "fp8", 6, 4e-3)],
+                         ids=["config3_dit_b2_bf16", "config5_dit_xl2_fp8"])
+def test_wide_dit_loss_curve_overlays(preset, dtype, steps, tol):
+    """the tight end-to-end check for BASELINE configs 3 and 5 -- per-step loss of the HIP path against the
+    fp32 CPU oracle over AdamW steps from the same weights and injected draws, at the configs' exact widths (768 / 12 heads;
+    1152 / 16 heads of dim 72, fp8 block Linears with delayed scaling), depth cut to 2, batch 8.  Tolerances from the measured
+    12-step runs (profiles/r04_loss_curve_dit_b2_d2_bf16.csv: 1.3e-4; r04_loss_curve_dit_xl2_d2_fp8.csv: 1.0e-3; the bf16 run of
+    the XL width: 3.2e-4), with a factor of 4-8 for other boxes' atomics order."""
+    from tests.loss_curve_overlay import main_dit
+
+    rows, dev = main_dit(steps=steps, dtype=dtype, B=8, preset=preset, depth=2)
+    assert rows[-1][1] < rows[0][1]
+    assert dev < tol, dev
+
+
+def test_sdxl_width_unet_loss_curve_overlay():
+    """The same for BASELINE config 4's denoiser: the SDXL-width UNet (320 / 640 / 1280, 77 x 2048 context, text_time conditioning;
+    transformer depth cut to 1 / 2 / 2) at 4x32x32 latents, bf16, batch 2, 5 AdamW steps against oracle/unet.py in fp32.
+    Measured over 8 steps: 1.7e-3 (profiles/r04_loss_curve_unet_sdxl_width_bf16.csv)."""
+    from tests.loss_curve_overlay import main_unet_sdxl_width
+
+    rows, dev = main_unet_sdxl_width(steps=5, dtype="bf16")
+    assert rows[-1][1] < rows[0][1]
+    assert dev < 6e-3, dev
+
+
 def test_checkpoint_resume_reproduces_the_run(tmp_path):
     """Save after 3 steps (Lightning checkpoint layout: `state_dict` with `unet.*` keys, `optimizer_states`,
     `lr_schedulers`, `global_step`), resume in fresh objects, and take the same steps 4-5 as the uninterrupted run;

@@ -919,12 +919,8 @@ int uwu_attn_mfma_bwd(const void* q, const void* k, const void* v, const void* o
   a.kbias = kbias;
   a.B = B; a.T = T; a.Tk = Tk; a.H = H; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.scale = scale;
   {
-    static int rowstore = -1;  // UWU_ATTN_ROWSTORE=0: direct 8-byte dK / dV stores (A/B comparisons)
-    if (rowstore < 0) {
-      const char* e = getenv("UWU_ATTN_ROWSTORE");
-      rowstore = (e && e[0] == '0') ? 0 : 1;
-    }
-    a.ldt = rowstore ? 0 : -99;
+    static UwuEnv rs("UWU_ATTN_ROWSTORE");  // UWU_ATTN_ROWSTORE=0: direct 8-byte dK / dV stores (A/B comparisons)
+    a.ldt = rs.get().is('0') ? -99 : 0;
   }
   if (d == 64) launch_bwd<64>(a, st);
   else if (d == 72) launch_bwd<72>(a, st);

@@ -603,27 +603,22 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_p256(const FArgs a) {
 
 bool uwu_attn_p256_ok(int T, int Tk, int d, int ldq, int ldk, int ldv, int ldo) {
   static UwuEnv on("UWU_ATTN_P256");  // "0": the one-workgroup-per-head kernel of attention_mfma.hip (A/B comparisons)
-  return !on.get().is('0') && T == 256 && Tk == 256 && d == 64 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0;
+  // (a device that cannot give one workgroup P_LDS bytes falls through to the per-head kernels of attention_mfma.hip)
+  return !on.get().is('0') && T == 256 && Tk == 256 && d == 64 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 &&
+         uwu_dev_lds_fits(P_LDS) && uwu_dev_cus() > 0;
 }
 
 int uwu_attn_p256_bwd(const void* q, const void* k, const void* v, const void* o, const void* dO, const float* lse, void* dq,
                       void* dk, void* dv, int B, int H, int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t st) {
-  static int n_cu = 0;
-  static bool once = false;
-  if (!once) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-      uwu_set_error("attention_bwd(p256): cannot query the device");
-      return UWU_ELAUNCH;
-    }
-    n_cu = prop.multiProcessorCount;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_p256<0>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_p256<1>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_p256<2>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_p256<3>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_p256<4>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
-    once = true;
+  static unsigned char done[5][UWU_MAX_DEV];  // per kernel instance, per device
+  const int n_cu = uwu_dev_cus();
+  if (n_cu <= 0 || !uwu_func_lds(reinterpret_cast<const void*>(attn_bwd_p256<0>), P_LDS, done[0]) ||
+      !uwu_func_lds(reinterpret_cast<const void*>(attn_bwd_p256<1>), P_LDS, done[1]) ||
+      !uwu_func_lds(reinterpret_cast<const void*>(attn_bwd_p256<2>), P_LDS, done[2]) ||
+      !uwu_func_lds(reinterpret_cast<const void*>(attn_bwd_p256<3>), P_LDS, done[3]) ||
+      !uwu_func_lds(reinterpret_cast<const void*>(attn_bwd_p256<4>), P_LDS, done[4])) {
+    uwu_set_error("attention_bwd(p256): the device cannot give a workgroup %d bytes of LDS", (int)P_LDS);
+    return UWU_ELAUNCH;
   }
   PArgs a{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o; a.dO = (const bf16_t*)dO;
@@ -650,23 +645,17 @@ bool uwu_attn_p256_fwd_ok(int nheads, int T, int Tk, int d, int ldq, int ldk, in
   // against 16.0 for the two-workgroups-per-head kernel) and the lack of a second workgroup per CU cost more than the
   // streaming gains (768 heads: 28.6 vs 27.0 us; 4608: 155 vs 160).  The backward wins at every size (96 heads: 19 vs 23 us).
   if (!on.is('1') && nheads < 1024) return false;
-  return T == 256 && Tk == 256 && d == 64 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0;
+  return T == 256 && Tk == 256 && d == 64 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && uwu_dev_lds_fits(F_LDS) &&
+         uwu_dev_cus() > 0;
 }
 
 int uwu_attn_p256_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int ldq, int ldk, int ldv,
                       int ldo, float scale, hipStream_t st) {
-  static int n_cu = 0;
-  static bool once = false;
-  if (!once) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-      uwu_set_error("attention_fwd(p256): cannot query the device");
-      return UWU_ELAUNCH;
-    }
-    n_cu = prop.multiProcessorCount;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_p256), hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
-    once = true;
+  static unsigned char done[UWU_MAX_DEV];
+  const int n_cu = uwu_dev_cus();
+  if (n_cu <= 0 || !uwu_func_lds(reinterpret_cast<const void*>(attn_fwd_p256), F_LDS, done)) {
+    uwu_set_error("attention_fwd(p256): the device cannot give a workgroup %d bytes of LDS", (int)F_LDS);
+    return UWU_ELAUNCH;
   }
   FArgs a{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)o; a.lse = lse;

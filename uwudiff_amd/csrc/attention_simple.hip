@@ -314,12 +314,8 @@ int uwu_attn_mfma_bwd(const void* q, const void* k, const void* v, const void* o
                       float* delta, const float* kbias, void* dq, void* dk, void* dv, int B, int T, int Tk, int H,
                       int d, int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t st);
 static bool force_simple() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("UWU_ATTN_SIMPLE");
-    v = (e && e[0] == '1') ? 1 : 0;
-  }
-  return v == 1;
+  static UwuEnv on("UWU_ATTN_SIMPLE");
+  return on.get().is('1');
 }
 
 static int check_common(const void* q, const void* k, const void* v, int B, int Tq, int Tk, int H, int d, int ldq,

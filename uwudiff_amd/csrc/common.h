@@ -37,29 +37,14 @@ void uwu_set_error(const char* fmt, ...);
     }                                                                           \
   } while (0)
 
-// ---- environment switches (A/B comparisons, sweeps, tests) --------------------------------------------------
-// Read once per switch and cached: a launch does not call getenv().  uwu_env_refresh() (api.cpp) bumps the generation so
-// that the next use re-reads -- the tests flip switches inside one process.
-int uwu_env_generation();
-struct UwuEnv {
-  const char* name;
-  int gen = -1, ival = 0;
-  bool set = false;
-  char c0 = 0;
-  explicit UwuEnv(const char* n) : name(n) {}
-  const UwuEnv& get() {
-    const int g = uwu_env_generation();
-    if (gen != g) {
-      const char* e = getenv(name);
-      set = e != nullptr;
-      c0 = e ? e[0] : 0;
-      ival = e ? atoi(e) : 0;
-      gen = g;
-    }
-    return *this;
-  }
-  bool is(char c) const { return set && c0 == c; }
-};
+#include "env.h"
+
+// ---- per-device facts (api.cpp): CU count, opt-in LDS, per-device hipFuncSetAttribute -------------------------------------
+int uwu_dev_index();
+int uwu_dev_cus();
+bool uwu_dev_lds_fits(size_t bytes);
+constexpr int UWU_MAX_DEV = 64;
+bool uwu_func_lds(const void* fn, size_t bytes, unsigned char* done /* UWU_MAX_DEV flags, zero-initialised */);
 
 // ---- live profiler hooks (prof.cpp) ------------------------------------------------------
 int uwu_prof_begin(void* stream);

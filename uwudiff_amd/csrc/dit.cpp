@@ -14,6 +14,7 @@
 #include <stdlib.h>
 
 #include "../../include/uwu_hip.h"
+#include "env.h"
 
 void uwu_set_error(const char* fmt, ...);
 
@@ -193,12 +194,8 @@ int lin_fwd(const void* X, const void* W, const float* bias, void* Y, void* Y2, 
   return uwu_gemm(X, W, Y, Y2, bias, nullptr, M, N, K, K, K, N, 0, 0, 0, dt, cdt, epi, 1, st);
 }
 static bool fc2_dgrad_as() {  // UWU_DIT_FC2DG_AS=0: the 256x256 kernel on the K-major weight (A/B comparisons)
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("UWU_DIT_FC2DG_AS");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v == 1;
+  static UwuEnv on("UWU_DIT_FC2DG_AS");  // (UwuEnv: re-read after uwu_env_refresh(), so in-process A/B runs compare two paths)
+  return !on.get().is('0');
 }
 // the fp32 conditioning Linears ([B, *] rows): matrix-vector kernels when the shape is covered (csrc/skinny.hip)
 int lin_fwd32(const float* X, const float* W, const float* bias, float* Y, float* Y2, int M, int N, int K, int epi, void* st) {
@@ -219,12 +216,8 @@ int lin_dgrad(const void* dY, const void* W, void* dX, const void* aux, int M, i
 // like every other one (Lightning precision "bf16-mixed", configs/demo_training_latent.yaml); the fp32 parity mode and small
 // batches (where the matrix-vector kernels take the conditioning Linears) are unchanged.  UWU_DIT_MOD_BF16=0: off (A/B).
 static bool mod_bf16(const uwu_dit_desc& d) {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("UWU_DIT_MOD_BF16");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v == 1 && d.dtype == UWU_BF16 && d.B >= 64 && d.mod_total % 8 == 0;
+  static UwuEnv on("UWU_DIT_MOD_BF16");
+  return !on.get().is('0') && d.dtype == UWU_BF16 && d.B >= 64 && d.mod_total % 8 == 0;
 }
 // dX[M,K] = dY[M,N] . W[N,K] for a LONG reduction N and few rows M (the batched adaLN linear: N = L*6*D+2*D):
 // split the reduction over workgroups and accumulate with fp32 atomics into a zeroed dX.
@@ -354,12 +347,8 @@ static int ln_fwd_f8(const uwu_dit_desc& d, const F8& f, const void* x_in, const
   return rc == UWU_OK ? 0 : rc;
 }
 static bool f8_emit(const uwu_dit_desc& d) {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("UWU_F8_EMIT");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v == 1 && d.fp8 == 2;
+  static UwuEnv on("UWU_F8_EMIT");
+  return !on.get().is('0') && d.fp8 == 2;
 }
 
 // ---- small batches: weight gradients on a second stream --------------------------------------------------------------

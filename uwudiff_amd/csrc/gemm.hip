@@ -2090,10 +2090,10 @@ template <int EPI, int FA>
 int launch_f8_emit(GemmArgs g, const float* sa, const float* sb, hipStream_t st) {
   auto kern = gemm_f8_kernel<bf16_t, EPI, FA, false, true>;
   constexpr int LDS = F8_EMIT_LDS > 2 * 4 * TILE_BYTES ? F8_EMIT_LDS : 2 * 4 * TILE_BYTES;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_done = true;
+  static unsigned char done[UWU_MAX_DEV];  // per device (141 KB of LDS: not every part has it)
+  if (!uwu_func_lds(reinterpret_cast<const void*>(kern), LDS, done)) {
+    uwu_set_error("gemm_f8(emit): the device cannot give a workgroup %d bytes of LDS", LDS);
+    return UWU_ELAUNCH;
   }
   g.tiles_m = (g.M + 255) / 256;
   g.tiles_n = (g.N + 255) / 256;

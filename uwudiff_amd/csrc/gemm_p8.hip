@@ -434,25 +434,19 @@ __global__ void __launch_bounds__(512, 2) gemm_p8_kernel(const GemmArgs g) {
 // workgroups of the persistent grid: one per CU of the current device (a multiple of 8, so that a workgroup's tiles stay on
 // one XCD chunk); UWU_P8_GRID=n overrides (sweeps)
 int p8_cus() {
-  static int cus[16] = {0};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= 16) dev = 0;
-  if (!cus[dev]) {
-    hipDeviceProp_t prop;
-    cus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8 ? prop.multiProcessorCount & ~7 : 256;
-  }
   static UwuEnv ge("UWU_P8_GRID");
-  return ge.get().set && ge.ival >= 8 ? ge.ival & ~7 : cus[dev];
+  if (ge.get().set && ge.ival >= 8) return ge.ival & ~7;
+  const int cus = uwu_dev_cus();
+  return cus >= 8 ? cus & ~7 : 256;
 }
 
 template <typename TC, int EPI, bool TB, int ABL = 0>
 int launch_p8(GemmArgs g, hipStream_t st) {
   auto kern = gemm_p8_kernel<TC, EPI, TB, ABL>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
-    attr_done = true;
+  static unsigned char done[UWU_MAX_DEV];
+  if (!uwu_func_lds(reinterpret_cast<const void*>(kern), P8_LDS, done)) {
+    uwu_set_error("gemm_p8: the device cannot give a workgroup %d bytes of LDS", P8_LDS);
+    return UWU_ELAUNCH;
   }
   g.tiles_m = (g.M + 255) / 256;
   g.tiles_n = (g.N + 255) / 256;
@@ -474,7 +468,7 @@ int launch_p8(GemmArgs g, hipStream_t st) {
 // (tests, A/B comparisons); default: K >= 512 and at least one tile per CU.
 bool uwu_gemm_p8_ok(const GemmArgs& g, bool tb) {
   static UwuEnv on("UWU_GEMM_P8"), kmin_e("UWU_P8_KMIN");
-  if (on.get().is('0')) return false;
+  if (on.get().is('0') || !uwu_dev_lds_fits(P8_LDS)) return false;
   if (g.K % 64 || g.K < 128) return false;
   if ((((uintptr_t)g.A | (uintptr_t)g.B) & 15) || g.lda % 8 || g.ldb % 8) return false;
   if (tb && (g.N % 8 || g.N < 8)) return false;

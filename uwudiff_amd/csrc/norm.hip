@@ -736,12 +736,8 @@ extern "C" int uwu_add_ln_modulate_fwd(const void* x_in, const void* y, const fl
 }
 
 static bool small_ln_on() {  // UWU_LN_SMALL=0: the 4-wave kernel at every size (A/B comparisons)
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("UWU_LN_SMALL");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v == 1;
+  static UwuEnv on("UWU_LN_SMALL");
+  return !on.get().is('0');
 }
 
 extern "C" int uwu_add_ln_modulate_bwd(const void* dh, const void* x, const float* mean, const float* rstd,
@@ -756,20 +752,14 @@ extern "C" int uwu_add_ln_modulate_bwd(const void* dh, const void* x, const floa
   const int M = B * T;
   hipStream_t st = (hipStream_t)stream;
   UWU_CHECK_ARG(dtype == UWU_F32 || dtype == UWU_BF16, "add_ln_modulate_bwd: bad dtype");
-  static int aff_on = -1;  // UWU_LN_AFFINE=0: the per-sample kernel for every case (A/B comparisons)
-  if (aff_on < 0) {
-    const char* e = getenv("UWU_LN_AFFINE");
-    aff_on = (e && e[0] == '0') ? 0 : 1;
-  }
+  static UwuEnv aff_e("UWU_LN_AFFINE");  // UWU_LN_AFFINE=0: the per-sample kernel for every case (A/B comparisons)
+  const bool aff_on = !aff_e.get().is('0');
   if (aff_on && affine && mod_ld == 0 && scale && !y && dshift && dscale && D <= 2048 && (dx_in == nullptr || ((uintptr_t)dx_in & 15) == 0)) {
     // one weight / bias vector for every row: 8-wave workgroups, LDS-folded column sums
     int rpb = M >= 16384 ? 64 : (M >= 4096 ? 32 : 16);
     {
-      static int forced = -1;
-      if (forced < 0) {
-        const char* e = getenv("UWU_LN_ROWS");
-        forced = e ? atoi(e) : 0;
-      }
+      static UwuEnv rows_e("UWU_LN_ROWS");
+      const int forced = rows_e.get().set ? rows_e.ival : 0;
       if (forced > 0) rpb = forced;
     }
     const int grid = (M + rpb - 1) / rpb;
@@ -822,11 +812,8 @@ extern "C" int uwu_add_ln_modulate_bwd(const void* dh, const void* x, const floa
   if (small) rows = 16;
   while (!small && rows > 4 && M / rows < 1024) rows >>= 1;
   {
-    static int forced = -1;
-    if (forced < 0) {
-      const char* e = getenv("UWU_LN_ROWS");
-      forced = e ? atoi(e) : 0;
-    }
+    static UwuEnv rows_e("UWU_LN_ROWS");
+    const int forced = rows_e.get().set ? rows_e.ival : 0;
     if (forced > 0 && T % forced == 0) rows = forced;
   }
   const size_t lds = (size_t)(small ? 8 : (D > 1024 ? 1 : 4)) * 3 * D * sizeof(float);  // (D > 1024: MAX_IT >= 3, one slab)

@@ -62,6 +62,97 @@ __global__ void rf_time_kernel(const float* __restrict__ u01, float smax, const 
   coef[4 * b + 3] = 0.f;
 }
 
+// ---- in-kernel draws (diffusion.py:68-76: noise = randn_like(x), then t = randint(0, N, [B]); rectified_flow.py:37: rand(B)) ------
+// Philox4x32-10 (Salmon, Moraes, Dror, Shaw, "Parallel random numbers: as easy as 1, 2, 3", SC'11): counter-based, so a draw needs
+// no state -- element group i of a tensor is philox(counter = offset + i, key = seed).  seed / offset come from the caller (the
+// host mirror takes them from torch's CUDA generator and advances its offset, so torch.manual_seed() reproduces a run); the
+// reference's ORDER of draws (noise before timesteps) is the order in which the host reserves offset ranges.  oracle/philox.py
+// restates the generator and the transforms; tests/test_objective_gpu.py compares bit for bit / to fp32 rounding.
+struct PhiloxOut { unsigned v[4]; };
+__device__ __forceinline__ PhiloxOut philox4x32_10(unsigned long long counter, unsigned long long seed) {
+  unsigned c0 = (unsigned)counter, c1 = (unsigned)(counter >> 32), c2 = 0u, c3 = 0u;
+  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    c0 = hi1 ^ c1 ^ k0;
+    c1 = lo1;
+    c2 = hi0 ^ c3 ^ k1;
+    c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return PhiloxOut{{c0, c1, c2, c3}};
+}
+// 24 random bits -> (0, 1): (r >> 8 + 1/2) / 2^24, exact in fp32
+__device__ __forceinline__ float philox_u01(unsigned r) { return ((float)(r >> 8) + 0.5f) * 5.9604644775390625e-08f; }
+// four N(0, 1) values from one counter: Box-Muller on the pairs (v0, v1) and (v2, v3)
+__device__ __forceinline__ f32x4 philox_normal4(unsigned long long counter, unsigned long long seed) {
+  const PhiloxOut o = philox4x32_10(counter, seed);
+  f32x4 z;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float rad = sqrtf(-2.f * __logf(philox_u01(o.v[2 * h])));
+    float sn, cs;
+    __sincosf(6.283185307179586f * philox_u01(o.v[2 * h + 1]), &sn, &cs);
+    z[2 * h] = rad * cs;
+    z[2 * h + 1] = rad * sn;
+  }
+  return z;
+}
+__global__ void philox_raw_kernel(unsigned* __restrict__ out, int64_t n, unsigned long long seed, unsigned long long offset) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const PhiloxOut o = philox4x32_10(offset + (unsigned long long)i, seed);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) out[4 * i + j] = o.v[j];
+}
+__global__ void philox_normal_kernel(float* __restrict__ out, int64_t total4, unsigned long long seed, unsigned long long offset) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < total4; i += stride) store4(out + 4 * i, philox_normal4(offset + (unsigned long long)i, seed));
+}
+// t[b] ~ U{0 .. n_train-1} (value j of counter offset + b / 4: (r * n_train) >> 32), then the gather of schedule_gather_kernel
+__global__ void schedule_draw_kernel(int64_t* __restrict__ t, int n_train, int B, unsigned long long seed,
+                                     unsigned long long offset) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const PhiloxOut o = philox4x32_10(offset + (unsigned long long)(b >> 2), seed);
+  t[b] = (int64_t)(((unsigned long long)o.v[b & 3] * (unsigned long long)n_train) >> 32);
+}
+__global__ void u01_draw_kernel(float* __restrict__ u, int B, unsigned long long seed, unsigned long long offset) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const PhiloxOut o = philox4x32_10(offset + (unsigned long long)(b >> 2), seed);
+  u[b] = philox_u01(o.v[b & 3]);
+}
+// q-sample with the noise drawn in the kernel: reads x, writes noise (the loss needs it again), noisy and -- with the VAE latent
+// normalisation -- x_norm: one pass instead of randn_like + q-sample
+__global__ void qsample_draw_kernel(const float* __restrict__ x, const float* __restrict__ coef, int64_t n4, int64_t total4,
+                                    int use_norm, float mean, float inv_std, float* __restrict__ x_norm,
+                                    float* __restrict__ noise, float* __restrict__ noisy, unsigned long long seed,
+                                    unsigned long long offset) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < total4; i += stride) {
+    const int b = (int)(i / n4);
+    const float sigma = coef[4 * b];
+    const float scale = 1.f / sqrtf(sigma * sigma + 1.f);
+    f32x4 xv = load4(x + 4 * i), o;
+    const f32x4 nv = philox_normal4(offset + (unsigned long long)i, seed);
+    if (use_norm) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xv[j] = (xv[j] - mean) * inv_std;
+      store4(x_norm + 4 * i, xv);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (xv[j] + nv[j] * sigma) * scale;
+    store4(noise + 4 * i, nv);
+    store4(noisy + 4 * i, o);
+  }
+}
+
 // diffusion.py:77-82 ; rectified_flow.py:67-71
 __global__ void qsample_kernel(const float* __restrict__ x, const float* __restrict__ noise,
                                const float* __restrict__ coef, int64_t n4, int64_t total4,
@@ -290,6 +381,47 @@ extern "C" int uwu_rf_time_to_sigma(const float* u01, float sigma_max, const flo
   hipLaunchKernelGGL(rf_time_kernel, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, u01, sigma_max,
                      log_sigmas_asc, n_train, B, coef, timesteps);
   UWU_LAUNCH_CHECK("rf_time_to_sigma");
+  return UWU_OK;
+}
+
+extern "C" int uwu_philox_raw(uint32_t* out, int64_t n_counters, uint64_t seed, uint64_t offset, void* stream) {
+  UWU_CHECK_ARG(out && n_counters > 0, "philox_raw: bad args");
+  hipLaunchKernelGGL(philox_raw_kernel, dim3(cdiv(n_counters, 256)), dim3(256), 0, (hipStream_t)stream, out, n_counters,
+                     (unsigned long long)seed, (unsigned long long)offset);
+  UWU_LAUNCH_CHECK("philox_raw");
+  return UWU_OK;
+}
+extern "C" int uwu_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream) {
+  UWU_CHECK_ARG(out && n > 0 && n % 4 == 0 && ((uintptr_t)out & 15) == 0, "philox_normal: n=%lld must be a positive multiple of 4", (long long)n);
+  hipLaunchKernelGGL(philox_normal_kernel, dim3(ew_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, out, n / 4,
+                     (unsigned long long)seed, (unsigned long long)offset);
+  UWU_LAUNCH_CHECK("philox_normal");
+  return UWU_OK;
+}
+extern "C" int uwu_draw_timesteps(int64_t* timesteps, int n_train, int B, uint64_t seed, uint64_t offset, void* stream) {
+  UWU_CHECK_ARG(timesteps && B > 0 && n_train > 0, "draw_timesteps: bad args");
+  hipLaunchKernelGGL(schedule_draw_kernel, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, timesteps, n_train, B,
+                     (unsigned long long)seed, (unsigned long long)offset);
+  UWU_LAUNCH_CHECK("draw_timesteps");
+  return UWU_OK;
+}
+extern "C" int uwu_draw_u01(float* u01, int B, uint64_t seed, uint64_t offset, void* stream) {
+  UWU_CHECK_ARG(u01 && B > 0, "draw_u01: bad args");
+  hipLaunchKernelGGL(u01_draw_kernel, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, u01, B, (unsigned long long)seed,
+                     (unsigned long long)offset);
+  UWU_LAUNCH_CHECK("draw_u01");
+  return UWU_OK;
+}
+extern "C" int uwu_qsample_draw(const float* x, const float* coef, int B, int64_t n, int use_norm, float vae_mean, float vae_std,
+                                float* x_norm, float* noise, float* noisy, uint64_t seed, uint64_t offset, void* stream) {
+  UWU_CHECK_ARG(x && coef && noise && noisy && (!use_norm || x_norm), "qsample_draw: null pointer");
+  UWU_CHECK_ARG(B > 0 && n > 0 && n % 4 == 0, "qsample_draw: n=%lld must be a positive multiple of 4", (long long)n);
+  UWU_CHECK_ARG(!use_norm || vae_std != 0.f, "qsample_draw: vae_std must be non-zero");
+  const int64_t total4 = (int64_t)B * n / 4;
+  hipLaunchKernelGGL(qsample_draw_kernel, dim3(ew_grid(total4, 256)), dim3(256), 0, (hipStream_t)stream, x, coef, n / 4, total4,
+                     use_norm, vae_mean, use_norm ? 1.f / vae_std : 1.f, x_norm, noise, noisy, (unsigned long long)seed,
+                     (unsigned long long)offset);
+  UWU_LAUNCH_CHECK("qsample_draw");
   return UWU_OK;
 }
 

@@ -43,12 +43,14 @@ __global__ void __launch_bounds__(256) sqnorm_final_kernel(const float* __restri
 // torch.optim.AdamW (single tensor, no amsgrad):
 //   p *= 1 - lr*wd ; m = lerp(m, g, 1-b1) ; v = b2*v + (1-b2) g^2 ;
 //   p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
-__global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+// zero_grad: the consumed gradient is overwritten with zeros in the same pass (the next backward accumulates into the flat
+// buffer: 4 more bytes written per parameter instead of a separate fill kernel that writes 4 and a launch)
+__global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v,
                                                     bf16_t* __restrict__ pbf, int64_t n, float lr, float b1,
                                                     float b2, float eps, float wd, float step_size,
                                                     float inv_bc2_sqrt, float pre_scale,
-                                                    const float* __restrict__ clip) {
+                                                    const float* __restrict__ clip, int zero_grad) {
   const float gscale = pre_scale * (clip ? clip[1] : 1.f);
   const int64_t n4 = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * 256;
@@ -71,6 +73,7 @@ __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const
     store4(m + 4 * i, mv);
     store4(v + 4 * i, vv);
     if (pbf) store4(pbf + 4 * i, pv);
+    if (zero_grad) store4(g + 4 * i, f32x4{0.f, 0.f, 0.f, 0.f});
   }
   if (blockIdx.x == 0) {
     for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) {
@@ -83,6 +86,7 @@ __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const
       m[i] = mm;
       v[i] = vn;
       if (pbf) pbf[i] = (bf16_t)pp;
+      if (zero_grad) g[i] = 0.f;
     }
   }
 }
@@ -111,9 +115,9 @@ extern "C" int uwu_grad_sqnorm_clip(const float* g, int64_t n, float pre_scale, 
   return UWU_OK;
 }
 
-extern "C" int uwu_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
+extern "C" int uwu_adamw_step(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
                               float beta1, float beta2, float eps, float weight_decay, int step, float pre_scale,
-                              const float* clip, void* stream) {
+                              const float* clip, int zero_grad, void* stream) {
   UWU_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "adamw_step: bad args");
   UWU_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
                 "adamw_step: buffers must be 16-byte aligned");
@@ -125,7 +129,7 @@ extern "C" int uwu_adamw_step(float* p, const float* g, float* m, float* v, void
   float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
   hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
                      (bf16_t*)p_bf16, n, lr, beta1, beta2, eps, weight_decay, step_size, inv_bc2_sqrt, pre_scale,
-                     clip);
+                     clip, zero_grad);
   UWU_LAUNCH_CHECK("adamw_step");
   return UWU_OK;
 }

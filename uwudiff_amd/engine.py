@@ -167,7 +167,10 @@ class Fitter:
                 return type(o)(snap(v) for v in o)
             return o
 
+        # "batches_in_epoch": how far into epoch `epoch` the run was (not inferred from global_step % len(loader),
+        # which is wrong once an epoch was cut short by max_steps or the loader length changes)
         ckpt = {"epoch": self.current_epoch, "global_step": self.global_step, "pytorch-lightning_version": "uwudiff_amd",
+                "batches_in_epoch": int(getattr(self, "batches_in_epoch", 0)),
                 "callbacks": callbacks or {},
                 "state_dict": snap(dict(module.state_dict())),
                 "optimizer_states": [snap(opt.state_dict())],
@@ -196,6 +199,7 @@ class Fitter:
             sched.load_state_dict(ckpt["lr_schedulers"][0])
         self.global_step = int(ckpt["global_step"])
         self.current_epoch = int(ckpt.get("epoch", 0))
+        self._resume_batches = ckpt.get("batches_in_epoch")  # None: a checkpoint of an earlier version
         saved = (ckpt.get("callbacks") or {}).get("ModelCheckpoint", {}).get("saved")
         if saved is not None:  # top-k pruning continues over the files the interrupted run had written
             for cb in self.callbacks:
@@ -244,21 +248,32 @@ class Fitter:
         epoch = self.current_epoch if ckpt_path is not None else 0  # a resumed run continues its epoch count (max_epochs, {epoch})
         done = False
         # resume mid-epoch like Lightning does: skip the batches the interrupted epoch had already consumed
-        resume_skip = (self.global_step % max(len(loader), 1)) if ckpt_path is not None else 0
-        if ckpt_path is not None and resume_skip == 0 and self.global_step > 0:
-            epoch += 1  # the checkpoint was written after the last batch of its epoch: that epoch is complete
+        n_batches = max(len(loader), 1)
+        resume_skip = 0
+        if ckpt_path is not None:
+            rb = getattr(self, "_resume_batches", None)
+            resume_skip = int(rb) if rb is not None else (self.global_step % n_batches)
+            if rb is None and resume_skip == 0 and self.global_step > 0:
+                resume_skip = n_batches  # (old checkpoints: written after the last batch of their epoch)
+            if resume_skip >= n_batches:
+                epoch += 1  # the checkpoint was written after the last batch of its epoch: that epoch is complete
+                resume_skip = 0
         self.current_epoch = epoch
+        self.batches_in_epoch = resume_skip
+        grads_zeroed = False
         while not done:
+            finished_epoch, ran = True, 0
             for bi, batch in enumerate(loader):
                 if bi < resume_skip:
                     continue
-                if 0 <= max_steps <= self.global_step:
-                    done = True
+                if 0 <= max_steps <= self.global_step:  # nothing left to do (resumed at max_steps)
+                    done, finished_epoch = True, False
                     break
                 module.global_step = self.global_step
-                for p in params:
-                    if p.grad is not None:
-                        p.grad.zero_()
+                if not grads_zeroed:  # (a fused step leaves the gradients zeroed: FusedAdamW.step(zero_grad=True))
+                    for p in params:
+                        if p.grad is not None:
+                            p.grad.zero_()
                 out = module.training_step(self._to_device(batch), self.global_step)
                 loss = out["loss"]
                 loss.backward()
@@ -268,9 +283,10 @@ class Fitter:
                     if self.gradient_clip_val:
                         sync.wait_all()
                         clip = opt.grad_norm_clip(self.gradient_clip_val, pre_scale=sync.pre_scale)
-                        opt.step(clip=clip, pre_scale=sync.pre_scale)
+                        opt.step(clip=clip, pre_scale=sync.pre_scale, zero_grad=True)
                     else:
-                        opt.step(pre_scale=sync.pre_scale, chunks=chunks, before_chunk=sync.wait_chunk)
+                        opt.step(pre_scale=sync.pre_scale, chunks=chunks, before_chunk=sync.wait_chunk, zero_grad=True)
+                    grads_zeroed = True
                 else:  # foreign optimizer (e.g. lion): plain torch path on the flat buffer
                     for p in params:
                         if self.world_size > 1:
@@ -285,6 +301,11 @@ class Fitter:
                 if sched is not None:
                     sched.step()
                 self.global_step += 1
+                ran += 1
+                self.batches_in_epoch = bi + 1
+                if 0 <= max_steps <= self.global_step:  # checked at the END of the step: no empty extra epoch afterwards
+                    done = True
+                    finished_epoch = bi + 1 >= n_batches
                 for hook in self.step_hooks:
                     hook(self)
                 for cb in ckpt_cbs:
@@ -295,10 +316,15 @@ class Fitter:
                     self.history.append(rec)
                     if self.global_rank == 0:
                         print(json.dumps(rec), flush=True)
+                if done:
+                    break
+            if not finished_epoch or (ran == 0 and resume_skip == 0 and done):
+                break  # cut short by max_steps: the epoch is partial -- no epoch-end hooks, no epoch count
             for cb in ckpt_cbs:
                 cb.on_epoch_end(self)
             epoch += 1
             self.current_epoch = epoch
+            self.batches_in_epoch = 0
             resume_skip = 0
             if self.max_epochs is not None and epoch >= self.max_epochs:
                 break

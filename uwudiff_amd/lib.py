@@ -46,6 +46,11 @@ _SIGS = {
     "uwu_schedule_gather": (c_int, [P, P, P, P, c_int, c_int, c_int, c_float, c_int, P, P]),
     "uwu_rf_time_to_sigma": (c_int, [P, c_float, P, c_int, c_int, P, P, P]),
     "uwu_qsample": (c_int, [P, P, P, c_int, c_int64, P, P, P]),
+    "uwu_philox_raw": (c_int, [P, c_int64, ctypes.c_uint64, ctypes.c_uint64, P]),
+    "uwu_philox_normal": (c_int, [P, c_int64, ctypes.c_uint64, ctypes.c_uint64, P]),
+    "uwu_draw_timesteps": (c_int, [P, c_int, c_int, ctypes.c_uint64, ctypes.c_uint64, P]),
+    "uwu_draw_u01": (c_int, [P, c_int, ctypes.c_uint64, ctypes.c_uint64, P]),
+    "uwu_qsample_draw": (c_int, [P, P, c_int, c_int64, c_int, c_float, c_float, P, P, P, ctypes.c_uint64, ctypes.c_uint64, P]),
     "uwu_qsample_norm": (c_int, [P, P, P, c_int, c_int64, c_float, c_float, P, P, P]),
     "uwu_ctx_place": (c_int, [P, c_int, P, P] + [c_int] * 7 + [P]),
     "uwu_loss_fwd_bwd": (c_int, [P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int64, P, P, P, P, P, P]),
@@ -58,7 +63,7 @@ _SIGS = {
     "uwu_scale_copy": (c_int, [P, P, c_int64, c_float, P]),
     "uwu_grad_sqnorm_clip": (c_int, [P, c_int64, c_float, c_float, P, P, P]),
     "uwu_adamw_step": (c_int, [P, P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float,
-                               P, P]),
+                               P, c_int, P]),
     "uwu_cast_f32_to_bf16": (c_int, [P, P, c_int64, P]),
     "uwu_cast_bf16_to_f32": (c_int, [P, P, c_int64, P]),
     "uwu_comm_unique_id": (c_int, [P]),

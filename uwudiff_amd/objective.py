@@ -19,6 +19,13 @@ from . import lib as L
 from .scheduler import EulerDiscreteScheduler
 
 
+class _PendingNoise:
+    """noise that the q-sample kernel will draw: the output tensor and the Philox counters reserved for it"""
+
+    def __init__(self, out, seed, offset):
+        self.out, self.seed, self.offset = out, seed, offset
+
+
 class DiffusionLossAuxOutput(NamedTuple):
     losses: torch.Tensor
     timesteps: torch.Tensor
@@ -136,12 +143,24 @@ class DiffusionLoss(nn.Module):
         assert self.prediction_type in ["epsilon", "v_prediction"]
         return 2 if self.prediction_type == "v_prediction" else 1
 
+    @staticmethod
+    def _reserve(device, n_counters):
+        """(seed, offset) of ``n_counters`` Philox counters taken from torch's CUDA generator of ``device`` (whose offset moves on
+        by them, rounded up to its granule of 4): the in-kernel draws follow ``torch.manual_seed`` like torch's own, and the ORDER
+        of reservations is the reference's order of draws (noise before timesteps, diffusion.py:75-76 / :68-70)."""
+        gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+        seed, off = gen.initial_seed() & ((1 << 64) - 1), gen.get_offset()
+        gen.set_offset(off + (int(n_counters) + 3) // 4 * 4)
+        return seed, off
+
     # diffusion.py:53-72
     def sample_timesteps_and_sigmas(self, ref_params: torch.Tensor):
         B = ref_params.size(0)
         t = self._take_injected("timesteps")
-        if t is None:
-            t = torch.randint(0, self.scheduler.config.num_train_timesteps, (B,), device=ref_params.device)
+        if t is None:  # t ~ U{0 .. N-1}, drawn by the library's Philox kernel (diffusion.py:68-70)
+            t = torch.empty(B, device=ref_params.device, dtype=torch.int64)
+            seed, off = self._reserve(ref_params.device, (B + 3) // 4)
+            L.call("uwu_draw_timesteps", L.ptr(t), int(self.scheduler.config.num_train_timesteps), B, seed, off, L.stream())
         t = t.to(device=ref_params.device, dtype=torch.int64).contiguous()
         debias = 0
         if self.use_debiased_estimation:
@@ -166,6 +185,14 @@ class DiffusionLoss(nn.Module):
 
     def _qsample_normed(self, x, noise, coef):
         """(clean latent the loss sees, noisy latent); with a latent normalisation set both come out of one kernel."""
+        if isinstance(noise, _PendingNoise):  # not injected: drawn inside the q-sample kernel (one pass writes noise + noisy)
+            use_norm = self._latent_norm is not None
+            mean, std = self._latent_norm if use_norm else (0.0, 1.0)
+            xn = torch.empty_like(x) if use_norm else None
+            noisy = torch.empty_like(x)
+            L.call("uwu_qsample_draw", L.ptr(x), L.ptr(coef), x.shape[0], x[0].numel(), int(use_norm), float(mean), float(std),
+                   L.ptr(xn), L.ptr(noise.out), L.ptr(noisy), noise.seed, noise.offset, L.stream())
+            return (xn if use_norm else x), noisy
         if self._latent_norm is None:
             return x, self._qsample(x, noise, coef)
         mean, std = self._latent_norm
@@ -174,11 +201,20 @@ class DiffusionLoss(nn.Module):
                L.ptr(noisy), L.stream())
         return xn, noisy
 
-    def _noise_like(self, x):
+    def _noise_like(self, x, now=False):
+        """Injected noise, or -- diffusion.py:75 ``randn_like(x)`` -- N(0, 1) from the library's Philox kernels: the counters are
+        reserved HERE (before the timesteps', the reference's order); the values are written by the q-sample kernel itself
+        unless ``now`` asks for the tensor at once (rescale_noise needs its statistics first)."""
         n = self._take_injected("noise")
-        if n is None:
-            return torch.randn_like(x)
-        return n.to(device=x.device, dtype=torch.float32).contiguous()
+        if n is not None:
+            return n.to(device=x.device, dtype=torch.float32).contiguous()
+        assert x.numel() % 4 == 0
+        seed, off = self._reserve(x.device, x.numel() // 4)
+        out = torch.empty_like(x)
+        if now:
+            L.call("uwu_philox_normal", L.ptr(out), out.numel(), seed, off, L.stream())
+            return out
+        return _PendingNoise(out, seed, off)
 
     # diffusion.py:169-193
     def forward(self, x: torch.Tensor, unet: nn.Module, **unet_kwargs):
@@ -189,6 +225,8 @@ class DiffusionLoss(nn.Module):
         timesteps, coef = self.sample_timesteps_and_sigmas(x)
         self._inject = None
         x, noisy = self._qsample_normed(x, noise, coef)
+        if isinstance(noise, _PendingNoise):
+            noise = noise.out
         model_output = unet(noisy, timesteps, **unet_kwargs)[0]
         # NB the reference hands the *clean* x to get_prediction_for_training as `xt` (diffusion.py:177)
         loss, losses, pred, target = _FusedLoss.apply(model_output, x, noise, x, coef, pt, tt, False)
@@ -221,8 +259,10 @@ class RectifiedFlowLoss(DiffusionLoss):
             raise ValueError(f"Unsupported time sampling type: {self.time_sampling_type}")
         B = ref_params.size(0)
         u = self._take_injected("u01")
-        if u is None:
-            u = torch.rand(B, device=ref_params.device)
+        if u is None:  # rectified_flow.py:37 ``torch.rand(B)``: the library's Philox kernel
+            u = torch.empty(B, device=ref_params.device, dtype=torch.float32)
+            seed, off = self._reserve(ref_params.device, (B + 3) // 4)
+            L.call("uwu_draw_u01", L.ptr(u), B, seed, off, L.stream())
         u = u.to(device=ref_params.device, dtype=torch.float32).contiguous()
         tb = self._dev_tables(ref_params.device)
         coef = torch.empty(B, 4, device=ref_params.device, dtype=torch.float32)
@@ -238,7 +278,7 @@ class RectifiedFlowLoss(DiffusionLoss):
             x = x[:, 0, ...].float().contiguous()
         else:
             x = x.float().contiguous()
-            noises = self._noise_like(x)
+            noises = self._noise_like(x, now=self.rescale_noise)
         if self.rescale_image:
             x = (x / x.std([1, 2, 3], keepdim=True) * 0.937).contiguous()
         if self.rescale_noise:
@@ -264,7 +304,14 @@ class RectifiedFlowLoss(DiffusionLoss):
         x, noises = self.get_x0_and_noises(x)
         timesteps, coef = self.sample_timesteps_and_sigmas(x)
         self._inject = None
-        if normed:
+        if isinstance(noises, _PendingNoise):  # drawn inside the q-sample kernel (a prenormalised x takes no second normalisation)
+            norm, self._latent_norm = self._latent_norm, (None if normed else self._latent_norm)
+            try:
+                x, noisy = self._qsample_normed(x, noises, coef)
+            finally:
+                self._latent_norm = norm
+            noises = noises.out
+        elif normed:
             noisy = self._qsample(x, noises, coef)
         else:
             x, noisy = self._qsample_normed(x, noises, coef)

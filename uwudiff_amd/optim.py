@@ -39,9 +39,11 @@ class FusedAdamW(torch.optim.Optimizer):
         return out
 
     @torch.no_grad()
-    def step(self, closure=None, clip=None, pre_scale=1.0, chunks=None, before_chunk=None):
+    def step(self, closure=None, clip=None, pre_scale=1.0, chunks=None, before_chunk=None, zero_grad=False):
         """One AdamW update.  ``chunks`` = [(offset, length), ...] splits the launch over sub-ranges of the flat
-        buffer (16-byte aligned offsets); ``before_chunk(i)`` is called first (waits for chunk i's all-reduce)."""
+        buffer (16-byte aligned offsets); ``before_chunk(i)`` is called first (waits for chunk i's all-reduce).
+        ``zero_grad``: the kernel leaves the consumed gradient zeroed (the flat gradient buffer is accumulated into by the
+        next backward: no separate fill launch; ``p.grad`` stays allocated -- the ``zero_grad(set_to_none=False)`` state)."""
         loss = closure() if closure is not None else None
         for group in self.param_groups:
             b1, b2 = group["betas"]
@@ -65,7 +67,7 @@ class FusedAdamW(torch.optim.Optimizer):
                     sp = shadow.data_ptr() + 2 * off if shadow is not None else None
                     L.call("uwu_adamw_step", ptrs[0], ptrs[1], ptrs[2], ptrs[3], sp, ln, float(group["lr"]), b1, b2,
                            group["eps"], group["weight_decay"], st["step"], float(pre_scale),
-                           L.ptr(clip) if clip is not None else None, L.stream())
+                           L.ptr(clip) if clip is not None else None, int(bool(zero_grad)), L.stream())
         return loss
 
 
