@@ -571,3 +571,62 @@ def test_gemm_p8_bench_shape_exact(monkeypatch):
     for _ in range(2):
         assert torch.equal(ops.gemm(a, b), want)
 
+
+# ---- 128 x 384 sibling (gemm_p8n.hip): N a multiple of 384 -- the N = 384 / 1152 Linears of DiT-S/2 and DiT-XL/2 -------------
+# UWU_GEMM_P8N=1 forces it on any shape it can run, =0 keeps the older kernels (UWU_GEMM_P8=0 as well: N = 768 / 1536 would go
+# to the 256 x 256 kernel first).  Same MFMA sequence per output element as every other bf16 kernel: bit-identical results.
+P8N_SHAPES = [(4096, 384, 384), (2048, 1152, 1536), (1000, 768, 256), (777, 384, 1152), (300, 1536, 640), (66000, 384, 384)]
+
+
+def _p8n_both(monkeypatch, fn):
+    monkeypatch.setenv("UWU_GEMM_P8", "0")
+    monkeypatch.setenv("UWU_GEMM_P8N", "0")
+    ref = fn()
+    monkeypatch.setenv("UWU_GEMM_P8N", "1")
+    return ref, fn()
+
+
+@pytest.mark.parametrize("M,N,K", P8N_SHAPES)
+def test_gemm_p8n_exact_integers(M, N, K, monkeypatch):
+    from uwudiff_amd import ops
+
+    monkeypatch.setenv("UWU_GEMM_P8", "0")
+    monkeypatch.setenv("UWU_GEMM_P8N", "1")
+    a, b = _operands(M, N, K, False, False, torch.bfloat16, ints=True, seed=71)
+    for _ in range(3):  # repeated launches: the ring's ordering must hold under different timings
+        c = ops.gemm(a, b)
+        assert torch.equal(c.float(), (a.float() @ b.float().t()).bfloat16().float())
+    dy, w = _operands(M, N, K, False, True, torch.bfloat16, ints=True, seed=72)
+    for _ in range(3):
+        c = ops.gemm(dy, w, trans_b=True)
+        assert torch.equal(c.float(), (dy.float() @ w.float()).bfloat16().float())
+
+
+@pytest.mark.parametrize("M,N,K", P8N_SHAPES)
+def test_gemm_p8n_matches_older_kernels(M, N, K, monkeypatch):
+    from uwudiff_amd import lib as L
+    from uwudiff_amd import ops
+
+    a, b = _operands(M, N, K, False, False, torch.bfloat16, ints=False, seed=73)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(74)).cuda()
+    for kw in ({}, dict(bias=bias, epilogue=L.EPI_BIAS)):
+        ref, got = _p8n_both(monkeypatch, lambda: ops.gemm(a, b, **kw))
+        assert torch.equal(ref, got)
+    (u0, f0), (u1, f1) = _p8n_both(monkeypatch, lambda: ops.gemm(a, b, bias=bias, epilogue=L.EPI_BIAS_GELU))
+    assert torch.equal(u0, u1) and torch.equal(f0, f1)
+    dy, w = _operands(M, N, K, False, True, torch.bfloat16, ints=False, seed=75)
+    ref, got = _p8n_both(monkeypatch, lambda: ops.gemm(dy, w, trans_b=True))
+    assert torch.equal(ref, got)
+
+
+def test_gemm_p8n_bench_shape_exact():
+    """DiT-S/2 qkv forward with bias at the bench's launch shape (4608 tiles: 18 per workgroup), exact integers, default dispatch."""
+    from uwudiff_amd import lib as L
+    from uwudiff_amd import ops
+
+    M, N, K = 196608, 1152, 384
+    a, b = _operands(M, N, K, False, False, torch.bfloat16, ints=True, seed=77)
+    bias = torch.randint(-3, 4, (N,), generator=torch.Generator().manual_seed(78)).float().cuda()
+    want = (a.float() @ b.float().t() + bias).bfloat16()
+    for _ in range(2):
+        assert torch.equal(ops.gemm(a, b, bias=bias, epilogue=L.EPI_BIAS), want)

@@ -1999,6 +1999,7 @@ int dispatch_trans(const GemmArgs& g, int ta, int tb, bool acc, int split, hipSt
   if (ta == 0 && tb == 0) {
     if constexpr (hot) {
       if (uwu_gemm_p8_ok(g, false)) return uwu_launch_gemm_p8(g, false, st);
+      if (g.N % 256 && uwu_gemm_p8n_ok(g, false)) return uwu_launch_gemm_p8n(g, false, st);
     }
     if constexpr (sizeof(T) == 2) {
       const int r3 = pick_r3(g, false);
@@ -2045,6 +2046,7 @@ int dispatch_trans(const GemmArgs& g, int ta, int tb, bool acc, int split, hipSt
   if (ta == 0 && tb == 1) {
     if constexpr (hot) {
       if (uwu_gemm_p8_ok(g, true)) return uwu_launch_gemm_p8(g, true, st);
+      if (g.N % 256 && uwu_gemm_p8n_ok(g, true)) return uwu_launch_gemm_p8n(g, true, st);
       const int r3 = pick_r3(g, true);
       if (r3 == 8 && use_wide(g) && g.epi == UWU_EPI_NONE) return launch_wide<TC, UWU_EPI_NONE, true>(g, st);
       if (r3 == 8 && use_big(g)) {

@@ -459,3 +459,6 @@ static double gemm_bytes(const GemmArgs& g, int es, int esc) {
 // the 8-phase 256 x 256 kernel (gemm_p8.hip): returns UWU_OK / error; `tb` = B is [K][N] (input gradients)
 int uwu_launch_gemm_p8(const GemmArgs& g, bool tb, hipStream_t st);
 bool uwu_gemm_p8_ok(const GemmArgs& g, bool tb);
+// its 128 x 384 sibling (gemm_p8n.hip): N a multiple of 384
+int uwu_launch_gemm_p8n(const GemmArgs& g, bool tb, hipStream_t st);
+bool uwu_gemm_p8n_ok(const GemmArgs& g, bool tb);
