@@ -752,15 +752,25 @@ class UNet2DConditionModel(nn.Module):
     def _attn(self, x, ctx, name, B, T, Tk, heads, key_bias=None):
         D = x.shape[1]
         if self.cfg_dict["rope"]:
-            # separate projections (the rotation needs q / k as tensors of their own), q rotated, k only in self-attention
             from .rope import _RopeFn
 
+            pos = self._rope_pos(B, self._hw, x.device)
+            fh, fw = _FlatParamFn.apply(self.flat, self.P, name + ".axial_rope.freqs_h"), _FlatParamFn.apply(self.flat, self.P, name + ".axial_rope.freqs_w")
+            d = D // heads
+            span = self.P.span([f"{name}.to_{c}.weight" for c in "qkv"]) if ctx is None else None
+            if span is not None and d == 64 and T % 64 == 0 and T <= 256 and self.P.bf16:
+                # self-attention up to 256 tokens (every one at 4x32x32 latents): ONE stacked projection and the rotation applied
+                # inside the attention kernels' q / k staging (attn_*_mfma<..., ROPE>, reference rope_unet.py:143-147 rotates
+                # between projection and SDPA) -- no rotated copies of q / k, no standalone rotation kernels in the forward
+                qkv = _LinearFn.apply(x, self.P, span, None, False, self.flat)
+                o = ops.rope_attention(qkv, pos[:T], fh, fw, B, T, heads, d)
+                return self._linear(o, name + ".to_out.0")
+            # longer sequences / cross-attention: separate projections (the rotation needs q / k as tensors of their own), q
+            # rotated, k only in self-attention
             q = self._linear(x, name + ".to_q", bias=False)
             src = x if ctx is None else ctx
             k = self._linear(src, name + ".to_k", bias=False)
             v = self._linear(src, name + ".to_v", bias=False)
-            pos = self._rope_pos(B, self._hw, x.device)
-            fh, fw = _FlatParamFn.apply(self.flat, self.P, name + ".axial_rope.freqs_h"), _FlatParamFn.apply(self.flat, self.P, name + ".axial_rope.freqs_w")
             q = _RopeFn.apply(q, pos, fh, fw, heads, D // heads)
             if ctx is None:
                 k = _RopeFn.apply(k, pos, fh, fw, heads, D // heads)
