@@ -345,7 +345,7 @@ def main():
             # same command, gfx950 corrections applied by tools/summarize_pmc.py).  The file names the kernel source
             # it was measured on; a number from other kernels is not reported.
             traffic, traffic_src = None, None
-            for tjn in ("r03_pmc_gemm_traffic.json", "r02_pmc_gemm_traffic.json"):
+            for tjn in ("r04_pmc_gemm_traffic.json", "r03_pmc_gemm_traffic.json"):
                 tj = os.path.join(ROOT, "profiles", tjn)
                 if traffic is None and args.dtype == "bf16" and B == DEFAULT_BATCH and args.model == MODEL and os.path.exists(tj) \
                         and not args.grad_checkpoint:
@@ -353,10 +353,10 @@ def main():
                         tjd = json.load(f)
                     if tjd.get("gemm_src_sha16") == src_sha16():
                         traffic = round(tjd["hbm_bytes_per_launch"])
-                        traffic_src = f"profiles/{tjn} (separate --pmc passes over this command, same gemm.hip)"
+                        traffic_src = f"profiles/{tjn} (separate --pmc passes over this command, same GEMM sources)"
             fam = ("fp8 block-scaled MFMA GEMM family (gemm_f8_kernel, v_mfma_scale_f32_16x16x128_f8f6f4: fwd + dgrad + split-K wgrad of the "
                    "block Linears; the few Linears outside the blocks stay bf16)" if args.dtype == "fp8" else
-                   "bf16 MFMA GEMM family (gemm_kernel / gemm_r3_kernel / gemm_big_kernel / gemm_wide_kernel / gemm_tr_kernel, "
+                   "bf16 MFMA GEMM family (gemm_as / gemm_wide / gemm_big / gemm_p8 / gemm_p8n / gemm_r3 / gemm_trw / gemm_tr kernels, "
                    "v_mfma_f32_16x16x32_bf16; fwd+dgrad+wgrad launches)")
             roof = {"bound": "mfma", "kernel": fam,
                     "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
@@ -449,11 +449,17 @@ def run_secondary(steps=5, warmup=2):
     return out
 
 
+GEMM_SOURCES = ("gemm_shared.h", "gemm.hip", "gemm_p8.hip", "gemm_p8n.hip")  # (tools/summarize_pmc.py hashes the same list)
+
+
 def src_sha16():
     import hashlib
 
-    with open(os.path.join(ROOT, "uwudiff_amd", "csrc", "gemm.hip"), "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()[:16]
+    h = hashlib.sha256()
+    for name in GEMM_SOURCES:
+        with open(os.path.join(ROOT, "uwudiff_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 if __name__ == "__main__":

@@ -32,11 +32,14 @@ def load(dirname, counter):
 
 fetch, nf, pf = load(sys.argv[1], "FETCH_SIZE")
 write, nw, pw = load(sys.argv[2], "WRITE_SIZE")
-_src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "uwudiff_amd", "csrc", "gemm.hip")
+_csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "uwudiff_amd", "csrc")
+_h = hashlib.sha256()
+for _name in ("gemm_shared.h", "gemm.hip", "gemm_p8.hip", "gemm_p8n.hip"):  # = bench.py GEMM_SOURCES
+    _h.update(open(os.path.join(_csrc, _name), "rb").read())
 out = {
-    "gemm_src_sha16": hashlib.sha256(open(_src, "rb").read()).hexdigest()[:16],  # bench.py reports the number only for this source
+    "gemm_src_sha16": _h.hexdigest()[:16],  # bench.py reports the number only for these sources
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline",
-    "kernel_family": "bf16 MFMA GEMM family: gemm_kernel / gemm_r3_kernel / gemm_big_kernel / gemm_wide_kernel / gemm_tr_kernel (+ splitk_reduce bytes), fwd + dgrad + wgrad launches",
+    "kernel_family": "bf16 MFMA GEMM family: every kernel with gemm in its name (+ splitk_reduce bytes), fwd + dgrad + wgrad launches",
     "launches": nf,
     "fetch_kib_sum_raw": fetch, "write_kib_sum": write,
     "hbm_bytes_per_launch": (2.0 * fetch / nf + write / nw) * 1024.0,
