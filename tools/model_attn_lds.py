@@ -169,6 +169,51 @@ for p in range(4):
     for l in range(64):
         assert (memE[addr[l] // 2: addr[l] // 2 + 8] == X[key[l], 8 * ch[l]:8 * ch[l] + 8]).all()
 
+# ================= head dim 72: the 8-column TAILS (16-byte rows) =================
+# a tile's tails: [row >> 3][Q 8 rows x 16 B | dO 8 rows x 16 B] (one LDS-DMA: lanes 0-7 of wave w write Q rows 8 w + lane at
+# 256 w + 16 lane, lanes 8-15 the dO rows); the K tail is [256 keys][16 B] row-major
+QT = rng.integers(1, 60000, size=(64, 8)).astype(np.uint16)
+GT = rng.integers(1, 60000, size=(64, 8)).astype(np.uint16)
+memT = np.zeros(2048 // 2, dtype=np.uint16)
+for w in range(8):
+    for ln in range(16):
+        src = QT if ln < 8 else GT
+        memT[(256 * w + 16 * ln) // 2: (256 * w + 16 * ln) // 2 + 8] = src[8 * w + (ln & 7)]
+TQ0 = (r >> 3) * 256 + (r & 7) * 16
+TA0 = rowL * 16 + 8 * (lanes & 1)
+for sub in range(2):
+    # (a) row read: fifth k step of S / dP: lane (r, h = 0) holds the 8 tail columns of row 32 sub + r (h = 1 reads the zero block)
+    for which, src in ((0, QT), (1, GT)):
+        addr = TQ0 + 1024 * sub + 128 * which
+        for l in range(32):
+            assert (memT[addr[l] // 2: addr[l] // 2 + 8] == src[32 * sub + r[l]]).all()
+        note("tail row b128 (lower half)", np.where(h == 0, addr, 4096), 16, B128_GROUPS, 64, 4)
+    # (b) transposing read: third row tile of dV^T / dK^T: lanes with (lane & 31) < 8 hold A[row d = 64 + (lane & 31)][k-slot (h, j)];
+    #     lanes 8-15 of a 16-lane group receive copies of columns 0..7, lanes 16-31 repeat lanes 0-15 (rows nobody stores)
+    for s2 in range(2):
+        for which, src in ((0, QT), (1, GT)):
+            frag = np.zeros((64, 8), dtype=np.uint16)
+            for sec in range(2):
+                addr = TA0 + 512 * s2 + 1024 * sub + 256 * sec + 128 * which
+                frag[:, 4 * sec:4 * sec + 4] = tr_read(memT, addr)
+                note("tail tr b64", addr, 8, HALVES, 64, 2)
+            for l in range(64):
+                for j in range(8):
+                    q = 32 * sub + 16 * s2 + 8 * (j >> 2) + 4 * h[l] + (j & 3)
+                    assert frag[l, j] == src[q, l & 7], (l, j)
+KTl = rng.integers(1, 60000, size=(256, 8)).astype(np.uint16)
+memKT = KTl.reshape(-1).copy()
+KT0 = rowK * 16 + 8 * (i16 & 1)
+for kk in range(8):  # A operand of the fifth d block of dQ^T: A[row = 64 + (l & 15)][k = 8 fq + j] = K[key 32 kk + 8 fq + j][64 + (l & 7)]
+    frag = np.zeros((64, 8), dtype=np.uint16)
+    for sec in range(2):
+        addr = KT0 + 512 * kk + 64 * sec
+        frag[:, 4 * sec:4 * sec + 4] = tr_read(memKT, addr)
+        note("K tail tr b64", addr, 8, HALVES, 64, 2)
+    for l in range(64):
+        for j in range(8):
+            assert frag[l, j] == KTl[32 * kk + 8 * fq[l] + j, i16[l] & 7]   # rows 8..15 of the block are copies of rows 0..7
+
 for k, (c, ideal) in conf.items():
     print(f"{k:28s} LDS cycles {c:5d}  conflict-free {ideal:5d}  {'OK' if c == ideal else f'{c / ideal:.2f}x'}")
 print("fragment contents: all lane maps verified")

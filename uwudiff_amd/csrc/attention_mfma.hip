@@ -901,7 +901,7 @@ int uwu_attn_mfma_fwd(const void* q, const void* k, const void* v, void* o, floa
 // T = 256, head dim 64, no key bias: the persistent LDS-DMA kernel (attention_p256.hip)
 bool uwu_attn_p256_ok(int T, int Tk, int d, int ldq, int ldk, int ldv, int ldo);
 int uwu_attn_p256_bwd(const void* q, const void* k, const void* v, const void* o, const void* dO, const float* lse, void* dq,
-                      void* dk, void* dv, int B, int H, int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t st);
+                      void* dk, void* dv, int B, int H, int d, int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t st);
 
 int uwu_attn_mfma_bwd(const void* q, const void* k, const void* v, const void* o, const void* dO, const float* lse,
                       float* delta, const float* kbias, void* dq, void* dk, void* dv, int B, int T, int Tk, int H,
@@ -911,7 +911,7 @@ int uwu_attn_mfma_bwd(const void* q, const void* k, const void* v, const void* o
                 "attention_bwd(mfma): tensors must be 16-byte aligned");
   (void)delta;  // the row sums of dO * O are formed inside the kernels
   if (!kbias && uwu_attn_p256_ok(T, Tk, d, ldq, ldk, ldv, ldo))
-    return uwu_attn_p256_bwd(q, k, v, o, dO, lse, dq, dk, dv, B, H, ldq, ldk, ldv, ldo, scale, st);
+    return uwu_attn_p256_bwd(q, k, v, o, dO, lse, dq, dk, dv, B, H, d, ldq, ldk, ldv, ldo, scale, st);
   MArgs a{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o;
   a.dO = (const bf16_t*)dO; a.lse = const_cast<float*>(lse); a.delta = delta;

@@ -26,12 +26,26 @@
 
 namespace {
 
-constexpr int P_RING = 3, P_SLOT = 16384;          // Q tile (8 KB) | dO tile (8 KB)
-constexpr int P_OFF_DS = P_RING * P_SLOT;            // dS^T image [256 keys][64 q] bf16
-constexpr int P_OFF_K = P_OFF_DS + 32768;            // 2 x K image [256 keys][64 d] (head parity)
-constexpr int P_OFF_LSE = P_OFF_K + 2 * 32768;       // 2 x lse[256] fp32 (head parity)
-constexpr int P_OFF_DELTA = P_OFF_LSE + 2 * 1024;    // 2 x -delta[64] fp32 (tile parity)
-constexpr int P_LDS = P_OFF_DELTA + 2 * 256;         // 150016 B
+constexpr int P_RING = 3;
+// LDS map of the backward for head dim DH (64, or 72 = 64 + an 8-column TAIL kept in compact 16-byte-row images):
+//   ring of P_RING slots: Q tile (8 KB) | dO tile (8 KB) [| tails [8 waves][Q 8 rows x 16 B | dO 8 rows x 16 B] | lse[64] of the tile]
+//   dS^T image [256 keys][64 q] bf16;  2 x K image [256 keys][64 d] [+ K tail [256 keys][8 d]] (head parity);
+//   (DH = 64) 2 x lse[256] (head parity);  2 x -delta[64] (tile parity)
+template <int DH>
+struct PGeom {
+  static constexpr bool TAIL = DH > 64;
+  static constexpr int SLOT = 16384 + (TAIL ? 2048 + 256 : 0);
+  static constexpr int OFF_TT = 16384, OFF_TL = 16384 + 2048;   // inside a slot: tails, lse piece
+  static constexpr int OFF_DS = P_RING * SLOT;
+  static constexpr int KIMG = 32768 + (TAIL ? 4096 : 0);
+  static constexpr int OFF_K = OFF_DS + 32768;
+  static constexpr int OFF_LSE = OFF_K + 2 * KIMG;
+  static constexpr int OFF_DELTA = OFF_LSE + (TAIL ? 0 : 2 * 1024);
+  static constexpr int OFF_ZERO = OFF_DELTA + 2 * 256;          // TAIL: 16 bytes of zeros
+  static constexpr int LDS = OFF_ZERO + (TAIL ? 16 : 0);        // 150016 B (DH = 64), 163088 B (DH = 72)
+};
+static_assert(PGeom<64>::LDS == 150016 && PGeom<72>::LDS <= 163840, "LDS budget");
+constexpr int P_LDS = PGeom<64>::LDS;
 
 struct PArgs {
   const bf16_t *q, *k, *v, *o, *dO;
@@ -120,9 +134,18 @@ __device__ __forceinline__ uint4 tr_pair(unsigned a0, unsigned a1) {
 
 // ABL (tools only, UWU_P256_ABL): timing-only builds with wrong results -- 1: no dQ product, 2: no global stores, 4: no phase 1
 // (dS^T image left stale)
-template <int ABL>
+// DH = 72 (DiT-XL/2's 16 heads of 1152): columns 64..71 of every operand travel as TAILS -- compact images with 16-byte rows next
+// to the 128-byte-row images of columns 0..63.  As a contraction index (S = Q.K^T, dP = dO.V^T) the tail is a fifth k step whose
+// upper half is zero in the K / V fragment registers; as an output index (dV^T, dK^T, dQ^T rows 64..71) it is a third / fifth row
+// tile whose rows past 71 hold garbage nobody stores (an MFMA row only ever sees its own row of A).
+template <int ABL, int DH = 64>
 __global__ void __launch_bounds__(512, 2) attn_bwd_p256(const PArgs a) {
-  constexpr int T = 256, DH = 64;
+  using G = PGeom<DH>;
+  constexpr bool TAIL = G::TAIL;
+  constexpr int T = 256, NKS = TAIL ? 5 : 4, NDT = TAIL ? 3 : 2;
+  constexpr int P_SLOT = G::SLOT, P_OFF_DS = G::OFF_DS, P_OFF_K = G::OFF_K, P_OFF_LSE = G::OFF_LSE, P_OFF_DELTA = G::OFF_DELTA;
+  constexpr int KIMG = G::KIMG;
+  static_assert(!TAIL || ABL == 0, "the timing-only ablations exist for head dim 64");
   char* const smem = p_smem;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -138,12 +161,43 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_p256(const PArgs a) {
   // per-lane pieces of the LDS addresses (tools/model_attn_lds.py derives and checks them)
   const int drow = tid >> 3;                             // DMA / delta: row of the 64-row tile this thread moves
   const int dchunk = (tid & 7) ^ fsw(drow);              // ... and the logical 16-byte chunk that lands at LDS byte 16 * tid
-  const unsigned B0 = (unsigned)(r * 128 + ((h ^ fsw(r)) << 4));  // row read: chunk 2 s + h of row r
-  const int rowL = 4 * h + ((lane & 15) >> 2), chunkL = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);
-  const unsigned A0 = (unsigned)(rowL * 128 + ((chunkL ^ fsw(rowL)) << 4) + 8 * (lane & 1));  // transposing read of a Q / dO tile
-  const int rowK = 8 * fq + (fr >> 2);
-  const unsigned K0 = (unsigned)(rowK * 128 + ((((fr & 3) >> 1) ^ fsw(rowK)) << 4) + 8 * (fr & 1));  // ... of the K image
-  const unsigned D0 = (unsigned)(rowK * 128 + (((fr & 3) ^ Fsw(rowK)) << 3));                         // ... of the dS^T image
+  // (TAIL: the head-dim-72 instance has no registers to park these in -- each phase rebuilds its own from a lane id the
+  // compiler cannot see through, a dozen VALU instructions per tile)
+  unsigned B0, A0, K0, D0, TQ0, TA0, KT0;
+  auto phase1_consts = [&](int ln) {
+    const int r_ = ln & 31, h_ = ln >> 5;
+    B0 = (unsigned)(r_ * 128 + ((h_ ^ fsw(r_)) << 4));  // row read: chunk 2 s + h of row r
+    const int rowL = 4 * h_ + ((ln & 15) >> 2), chunkL = 2 * ((ln >> 4) & 1) + ((ln & 3) >> 1);
+    A0 = (unsigned)(rowL * 128 + ((chunkL ^ fsw(rowL)) << 4) + 8 * (ln & 1));  // transposing read of a Q / dO tile
+    // tails (16-byte rows; a tile's tails sit as [row >> 3][Q 8 rows | dO 8 rows]): row read of row r, transposing read (rows
+    // 4 h + q, 8-byte half lane & 1; lanes 16-31 and columns past 8 repeat lanes 0-15 / columns 0-7: garbage rows)
+    TQ0 = (unsigned)((r_ >> 3) * 256 + (r_ & 7) * 16);
+    TA0 = (unsigned)(rowL * 16 + 8 * (ln & 1));
+  };
+  auto phase2_consts = [&](int ln) {
+    const int fr_ = ln & 15, fq_ = ln >> 4;
+    const int rowK = 8 * fq_ + (fr_ >> 2);
+    K0 = (unsigned)(rowK * 128 + ((((fr_ & 3) >> 1) ^ fsw(rowK)) << 4) + 8 * (fr_ & 1));  // transposing read of the K image
+    D0 = (unsigned)(rowK * 128 + (((fr_ & 3) ^ Fsw(rowK)) << 3));                         // ... of the dS^T image
+    KT0 = (unsigned)(rowK * 16 + 8 * (fr_ & 1));                                          // ... of the K tail (rows 8 fq + (fr >> 2))
+  };
+  auto opaque_lane = [&]() {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    return ln;
+  };
+  // (same idea for the per-lane parts of the global addresses: the TAIL instance rebuilds them where they are used instead of
+  // keeping a dozen hoisted 64-bit offsets alive -- those were the registers it spilled, and a spill reload inside the tile loop
+  // waits on the vector-memory counter, i.e. on the DMA ring)
+  auto my_tid = [&]() {
+    int x = tid;
+    if constexpr (TAIL) asm volatile("" : "+v"(x));
+    return x;
+  };
+  if constexpr (!TAIL) {
+    phase1_consts(lane);
+    phase2_consts(lane);
+  }
 
   auto head_ptrs = [&](int j, int& b, int& hd) {
     const int bh = (int)blockIdx.x + j * (int)gridDim.x;
@@ -151,10 +205,12 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_p256(const PArgs a) {
     hd = bh - b * a.H;
   };
   uint4 oreg;
+  unsigned otail = 0;  // TAIL: lanes (tid & 7) < 4 hold columns 64 + 2 (tid & 7), + 1 of their row's O
   // tile g = 4 j + t: rows 64 t .. 64 t + 63 of head j's Q and dO into ring slot g % 3; this thread's O chunk into oreg
   auto issue_tile = [&](int g) {
     int b, hd;
     head_ptrs(g >> 2, b, hd);
+    const int tid = my_tid(), lane = tid & 63, drow = tid >> 3, dchunk = (tid & 7) ^ fsw(drow);
     const int row = 64 * (g & 3) + drow;
     const bf16_t* qs = a.q + ((int64_t)b * T + row) * a.ldq + hd * DH + 8 * dchunk;
     const bf16_t* gs = a.dO + ((int64_t)b * T + row) * a.ldo + hd * DH + 8 * dchunk;
@@ -162,26 +218,56 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_p256(const PArgs a) {
     glds16(qs, dst);
     glds16(gs, dst + 8192);
     oreg = *reinterpret_cast<const uint4*>(a.o + ((int64_t)b * T + row) * a.ldo + hd * DH + 8 * dchunk);
+    if constexpr (TAIL) {
+      // one more operation moves both tails (lanes 0-7: Q rows 8 wave + lane, lanes 8-15: dO rows 8 wave + lane - 8), one the
+      // lse piece of the tile (every wave writes the same 256 bytes: equal instruction counts for every wave)
+      const unsigned slot = smem_base + (unsigned)((g % P_RING) * P_SLOT);
+      if (lane < 16) {
+        const int64_t trow = (int64_t)b * T + 64 * (g & 3) + 8 * wave + (lane & 7);
+        const bf16_t* src = lane < 8 ? a.q + trow * a.ldq + hd * DH + 64 : a.dO + trow * a.ldo + hd * DH + 64;
+        glds16(src, slot + (unsigned)(G::OFF_TT + wave * 256));
+      }
+      glds4(a.lse + ((int64_t)b * a.H + hd) * T + 64 * (g & 3) + lane, slot + (unsigned)G::OFF_TL);
+      // (no load, store or LDS-DMA the compiler counts sits behind a divergent branch in this kernel: a skippable operation makes
+      // its wait-count pass distrust the hand-counted wait at the top of the tile and add its own -- lanes 4-7 of a row repeat
+      // lanes 0-3 here and are masked in delta_of)
+      otail = *reinterpret_cast<const unsigned*>(a.o + ((int64_t)b * T + row) * a.ldo + hd * DH + 64 + 2 * (tid & 3));
+    }
   };
   // K image (4 pieces of 64 keys) and the lse row of head j
   auto issue_head = [&](int j) {
     int b, hd;
     head_ptrs(j, b, hd);
-    const unsigned dst = smem_base + (unsigned)(P_OFF_K + (j & 1) * 32768 + wave * 1024);
+    const int tid = my_tid(), lane = tid & 63, drow = tid >> 3, dchunk = (tid & 7) ^ fsw(drow);
+    const unsigned dst = smem_base + (unsigned)(P_OFF_K + (j & 1) * KIMG + wave * 1024);
 #pragma unroll
     for (int p = 0; p < 4; ++p)  // (fsw only looks at row bits 1-4: the swizzle of row 64 p + drow is that of drow)
       glds16(a.k + ((int64_t)b * T + 64 * p + drow) * a.ldk + hd * DH + 8 * dchunk, dst + p * 8192);
-    // 256 floats: waves w and w + 4 move the same 64 (equal instruction counts for every wave)
-    glds4(a.lse + ((int64_t)b * a.H + hd) * T + 64 * (wave & 3) + lane, smem_base + (unsigned)(P_OFF_LSE + (j & 1) * 1024 + (wave & 3) * 256));
+    if constexpr (TAIL) {  // K tail: wave w moves rows 32 w .. 32 w + 31 (the lse travels with the tiles)
+      if (lane < 32)
+        glds16(a.k + ((int64_t)b * T + 32 * wave + lane) * a.ldk + hd * DH + 64,
+               smem_base + (unsigned)(P_OFF_K + (j & 1) * KIMG + 32768 + wave * 512));
+    } else {
+      // 256 floats: waves w and w + 4 move the same 64 (equal instruction counts for every wave)
+      glds4(a.lse + ((int64_t)b * a.H + hd) * T + 64 * (wave & 3) + lane,
+            smem_base + (unsigned)(P_OFF_LSE + (j & 1) * 1024 + (wave & 3) * 256));
+    }
   };
-  uint4 kf[4], vf[4];
+  uint4 kf[NKS], vf[NKS];
   auto load_kv = [&](int j) {
     int b, hd;
     head_ptrs(j, b, hd);
+    const int tid = my_tid(), r = tid & 31, h = (tid >> 5) & 1;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       kf[s] = *reinterpret_cast<const uint4*>(a.k + ((int64_t)b * T + k0 + r) * a.ldk + hd * DH + 16 * s + 8 * h);
       vf[s] = *reinterpret_cast<const uint4*>(a.v + ((int64_t)b * T + k0 + r) * a.ldv + hd * DH + 16 * s + 8 * h);
+    }
+    if constexpr (TAIL) {  // k slots 0-7 of the fifth step are columns 64..71, slots 8-15 (the upper lane half) meet zeros
+      // (both lane halves load the eight real columns: the zeros of slots 8-15 are on the Q / dO side -- masking here would wait
+      // for these loads, and with them for the DMA ring, in the middle of a tile)
+      kf[4] = *reinterpret_cast<const uint4*>(a.k + ((int64_t)b * T + k0 + r) * a.ldk + hd * DH + 64);
+      vf[4] = *reinterpret_cast<const uint4*>(a.v + ((int64_t)b * T + k0 + r) * a.ldv + hd * DH + 64);
     }
   };
   // -delta[q] = -sum_d dO[q][d] O[q][d] of tile g (its dO is in LDS, its O chunk in oreg): 8 lanes per row
@@ -191,13 +277,23 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_p256(const PArgs a) {
     float ds = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) ds += (float)gv[e] * (float)ov[e];
+    if constexpr (TAIL) {
+      const unsigned gtc = *reinterpret_cast<const unsigned*>(smem + (g % P_RING) * P_SLOT + G::OFF_TT + (drow >> 3) * 256 + 128 +
+                                                              (drow & 7) * 16 + 4 * (tid & 3));
+      const bf16x2 gt2 = *reinterpret_cast<const bf16x2*>(&gtc), ot2 = *reinterpret_cast<const bf16x2*>(&otail);
+      const float dt2 = (float)gt2[0] * (float)ot2[0] + (float)gt2[1] * (float)ot2[1];
+      ds += (tid & 4) ? 0.f : dt2;
+    }
     ds += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ds), 0xB1, 0xF, 0xF, true));   // lane ^ 1
     ds += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ds), 0x4E, 0xF, 0xF, true));   // lane ^ 2
     ds += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ds), 0x141, 0xF, 0xF, true));  // half-row mirror
     if ((tid & 7) == 0) reinterpret_cast<float*>(smem + P_OFF_DELTA + (g & 1) * 256)[drow] = -ds;
   };
 
+  // (TAIL: rows 64..71 of dK^T / dV^T are registers 0..3 of a third row tile -- only those four are kept across tiles, the tile's
+  // own product lives in short-lived registers: 8 instead of 32 permanent ones)
   f32x16 dkT[2], dvT[2];
+  f32x4 dkt = {0.f, 0.f, 0.f, 0.f}, dvt = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt) dkT[dt] = dvT[dt] = f32x16{};
 
@@ -206,7 +302,9 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_p256(const PArgs a) {
   auto store_dkdv = [&](int j) {
     int b, hd;
     head_ptrs(j, b, hd);
-    char* mine = smem + P_OFF_K + (j & 1) * 32768 + wave * 4096;
+    const int tid = my_tid(), lane = tid & 63, r = tid & 31, h = (tid >> 5) & 1;
+    char* mine = smem + P_OFF_K + (j & 1) * KIMG + wave * 4096;
+    char* mine_t = smem + P_OFF_K + (j & 1) * KIMG + 32768 + wave * 512;  // TAIL: [32 keys][8 d]
 #pragma unroll
     for (int which = 0; which < 2; ++which) {
 #pragma unroll
@@ -228,13 +326,24 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_p256(const PArgs a) {
         if constexpr (!(ABL & 2)) *reinterpret_cast<uint4*>(dst + (int64_t)(k0 + key) * ld + 8 * ch) = x;
         else asm volatile("" ::"v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w));
       }
+      if constexpr (TAIL) {  // rows 64 + 4 h + i of the third tile are registers 0..3; the rest of it is garbage
+        const f32x4 x = which ? dvt : dkt;
+        const float sc = which ? 1.f : a.scale;
+        store4(reinterpret_cast<bf16_t*>(mine_t + r * 16 + 8 * h), f32x4{x[0] * sc, x[1] * sc, x[2] * sc, x[3] * sc});
+        // (lanes 32-63 repeat lanes 0-31: the same bytes to the same addresses)
+        const uint4 xt = *reinterpret_cast<const uint4*>(mine_t + r * 16);
+        *reinterpret_cast<uint4*>(dst + (int64_t)(k0 + r) * ld + 64) = xt;
+      }
     }
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) dkT[dt] = dvT[dt] = f32x16{};
+    dkt = dvt = f32x4{0.f, 0.f, 0.f, 0.f};
   };
 
   // ---- prologue: head 0's K image / lse / fragments and tile 0, then tile 1 behind the first delta
   if (total == 0) return;
+  if constexpr (TAIL)
+    if (tid < 4) reinterpret_cast<unsigned*>(smem + G::OFF_ZERO)[tid] = 0u;  // (the prologue's barrier publishes it)
   issue_head(0);
   issue_tile(0);
   load_kv(0);
@@ -255,7 +364,8 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_p256(const PArgs a) {
     const int j = g >> 2, t = g & 3;
     // [A] tile g + 1 (issued one iteration ago, with the K image / lse of its head if it opens one) has landed: every
     // vector-memory operation of this wave except the youngest one -- the dq store of tile g - 1 -- is complete
-    __builtin_amdgcn_s_waitcnt((ABL & 3) ? 0x0070 : 0x0071);  // vmcnt(1) lgkmcnt(0)  (timing builds without that store: vmcnt(0))
+    // (DH = 72: the dq tail is a second store -- two operations stay in flight)
+    __builtin_amdgcn_s_waitcnt(TAIL ? 0x0072 : (ABL & 3) ? 0x0070 : 0x0071);  // vmcnt(1) lgkmcnt(0)  (timing builds without that store: vmcnt(0))
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();  // [B] ... everybody's pieces; everybody has finished phase 2 of tile g - 1
     if (t == 0 && j > 0) store_dkdv(j - 1);
@@ -266,8 +376,10 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_p256(const PArgs a) {
     }
     // ---- [E] phase 1: this wave's 32 keys against the 64 query rows of tile g
     if constexpr (!(ABL & 4)) {
+      if constexpr (TAIL) phase1_consts(opaque_lane());
       const unsigned Qs = (unsigned)((g % P_RING) * P_SLOT), Gs = Qs + 8192;
-      const float* ls = reinterpret_cast<const float*>(smem + P_OFF_LSE + (j & 1) * 1024) + 64 * t;
+      const float* ls = TAIL ? reinterpret_cast<const float*>(smem + (g % P_RING) * P_SLOT + G::OFF_TL)
+                             : reinterpret_cast<const float*>(smem + P_OFF_LSE + (j & 1) * 1024) + 64 * t;
       const float* dl = reinterpret_cast<const float*>(smem + P_OFF_DELTA + (g & 1) * 256);
       char* const dsimg = smem + P_OFF_DS;
 #pragma unroll
@@ -292,6 +404,13 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_p256(const PArgs a) {
           S = mfma32(qa, kf[s], S);
           dP = mfma32(ga, vf[s], dP);
         }
+        if constexpr (TAIL) {  // the upper lane half (k slots 8-15) reads the 16 zero bytes
+          const unsigned off = Qs + (unsigned)G::OFF_TT + TQ0 + 1024u * sub;
+          const uint4 qa = *reinterpret_cast<const uint4*>(smem + (h ? (unsigned)G::OFF_ZERO : off));
+          const uint4 ga = *reinterpret_cast<const uint4*>(smem + (h ? (unsigned)G::OFF_ZERO : off + 128));
+          S = mfma32(qa, kf[4], S);
+          dP = mfma32(ga, vf[4], dP);
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const float p = __builtin_amdgcn_exp2f(S[i] * c);
@@ -310,6 +429,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_p256(const PArgs a) {
           const int key = k0 + r;
           *reinterpret_cast<uint2*>(dsimg + key * 128 + (((8 * sub + 2 * g4 + h) ^ Fsw(key)) << 3)) = w;
         }
+        f32x16 tv = {}, tk = {};  // TAIL: this sub-tile's rows 64..95 of dV^T / dK^T
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           const uint4 pf = pack8(S, s2);
@@ -327,6 +447,20 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_p256(const PArgs a) {
             dvT[dt] = mfma32(gt, pf, dvT[dt]);
             dkT[dt] = mfma32(qt, dsf, dkT[dt]);
           }
+          if constexpr (TAIL) {
+            const unsigned x0 = Qs + (unsigned)G::OFF_TT + TA0 + 512u * s2 + 1024u * sub;
+            const uint4 gt = tr_pair(x0 + 128u, x0 + 128u + 256u);
+            const uint4 qt = tr_pair(x0, x0 + 256u);
+            tv = mfma32(gt, pf, tv);
+            tk = mfma32(qt, dsf, tk);
+          }
+        }
+        if constexpr (TAIL) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            dvt[e] += tv[e];
+            dkt[e] += tk[e];
+          }
         }
       }
     }
@@ -336,10 +470,14 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_p256(const PArgs a) {
     __builtin_amdgcn_s_barrier();                       // [F] dS^T image complete
     // ---- [G] phase 2: dQ^T[d][q] = K^T[d][key] . dS^T[key][q]; wave w owns q-block w & 3 and d-blocks 2 (w >> 2), + 1
     if constexpr (!(ABL & 1)) {
+      if constexpr (TAIL) phase2_consts(opaque_lane());
       const int qblk = wave & 3, db0 = 2 * (wave >> 2);
-      const unsigned Ki = (unsigned)(P_OFF_K + (j & 1) * 32768), Di = (unsigned)P_OFF_DS;
+      const unsigned Ki = (unsigned)(P_OFF_K + (j & 1) * KIMG), Di = (unsigned)P_OFF_DS;
       const unsigned ka = K0 ^ (unsigned)(db0 << 5), kb = K0 ^ (unsigned)((db0 + 1) << 5), da = D0 ^ (unsigned)(qblk << 5);
-      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+      // (TAIL: waves w and w + 4 BOTH form rows 64..71 of query block w & 3 and store the same eight bytes per lane -- one
+      // instruction stream for every wave, so the hand-counted wait at the top of the tile needs no branch: behind one, hipcc's
+      // wait-count pass no longer trusted it and drained the DMA ring in front of the S / dP MFMAs of every tile)
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) {
         const unsigned ko = 4096u * kk;
@@ -348,6 +486,10 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_p256(const PArgs a) {
         const uint4 fd = tr_pair(Di + da + ko, Di + (da ^ 0x10u) + 512u + ko);
         acc0 = mfma16(fa, fd, acc0);
         acc1 = mfma16(fb, fd, acc1);
+        if constexpr (TAIL) {
+          const unsigned kt = Ki + 32768u + KT0 + 512u * kk;
+          acc2 = mfma16(tr_pair(kt, kt + 64u), fd, acc2);
+        }
       }
       // D[row = d = 16 db + 4 fq + reg][col = q = fr]: the lane holds 4 consecutive d of both d-blocks of one query row.
       // v_permlane16_swap pairs fq with fq ^ 1: even fq keeps d-block db0 (8 consecutive d), odd fq takes d-block db0 + 1
@@ -364,6 +506,12 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_p256(const PArgs a) {
       bf16_t* dst = a.dq + ((int64_t)b * T + 64 * t + 16 * qblk + fr) * a.ldq + hd * DH + d;
       if constexpr (!(ABL & 2)) *reinterpret_cast<uint4*>(dst) = uint4{sx[0], sy[0], sx[1], sy[1]};
       else asm volatile("" ::"v"(sx[0]), "v"(sy[0]), "v"(sx[1]), "v"(sy[1]), "v"(dst));
+      if constexpr (TAIL) {
+        // D[row = 64 + 4 fq + reg][col = q = fr]: lanes fq < 2 hold the eight real rows; the K tail's transposing reads fetch
+        // columns 0..7 twice, so rows 72..79 -- lanes fq >= 2 -- are copies of rows 64..71 and store the same bytes again
+        const f32x4 v2 = acc2 * a.scale;
+        store4(a.dq + ((int64_t)b * T + 64 * t + 16 * qblk + fr) * a.ldq + hd * DH + 64 + 4 * (fq & 1), v2);
+      }
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -604,14 +752,31 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_p256(const FArgs a) {
 bool uwu_attn_p256_ok(int T, int Tk, int d, int ldq, int ldk, int ldv, int ldo) {
   static UwuEnv on("UWU_ATTN_P256");  // "0": the one-workgroup-per-head kernel of attention_mfma.hip (A/B comparisons)
   // (a device that cannot give one workgroup P_LDS bytes falls through to the per-head kernels of attention_mfma.hip)
-  return !on.get().is('0') && T == 256 && Tk == 256 && d == 64 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 &&
-         uwu_dev_lds_fits(P_LDS) && uwu_dev_cus() > 0;
+  if (on.get().is('0') || T != 256 || Tk != 256 || ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8 || uwu_dev_cus() <= 0) return false;
+  if (d == 64) return uwu_dev_lds_fits(P_LDS);
+  static UwuEnv on72("UWU_ATTN_P256_D72");  // "0": head dim 72 stays on the key-block + dq kernels of attention_mfma.hip
+  return d == 72 && !on72.get().is('0') && uwu_dev_lds_fits(PGeom<72>::LDS);
 }
 
 int uwu_attn_p256_bwd(const void* q, const void* k, const void* v, const void* o, const void* dO, const float* lse, void* dq,
-                      void* dk, void* dv, int B, int H, int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t st) {
+                      void* dk, void* dv, int B, int H, int d, int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t st) {
   static unsigned char done[5][UWU_MAX_DEV];  // per kernel instance, per device
   const int n_cu = uwu_dev_cus();
+  if (d == 72) {
+    static unsigned char done72[UWU_MAX_DEV];
+    if (n_cu <= 0 || !uwu_func_lds(reinterpret_cast<const void*>(attn_bwd_p256<0, 72>), PGeom<72>::LDS, done72)) {
+      uwu_set_error("attention_bwd(p256, d = 72): the device cannot give a workgroup %d bytes of LDS", (int)PGeom<72>::LDS);
+      return UWU_ELAUNCH;
+    }
+    PArgs a{};
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o; a.dO = (const bf16_t*)dO;
+    a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.lse = lse;
+    a.B = B; a.H = H; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.nheads = B * H; a.scale = scale;
+    const int grid = a.nheads < n_cu ? a.nheads : n_cu;
+    hipLaunchKernelGGL((attn_bwd_p256<0, 72>), dim3(grid), dim3(512), PGeom<72>::LDS, st, a);
+    UWU_LAUNCH_CHECK("attention_bwd(p256, d = 72)");
+    return UWU_OK;
+  }
   if (n_cu <= 0 || !uwu_func_lds(reinterpret_cast<const void*>(attn_bwd_p256<0>), P_LDS, done[0]) ||
       !uwu_func_lds(reinterpret_cast<const void*>(attn_bwd_p256<1>), P_LDS, done[1]) ||
       !uwu_func_lds(reinterpret_cast<const void*>(attn_bwd_p256<2>), P_LDS, done[2]) ||
