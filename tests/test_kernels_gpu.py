@@ -173,6 +173,61 @@ def test_attention_fwd_bwd(B, Tq, Tk, H, d, packed, dtype):
     cmp(dv, vr.grad.transpose(1, 2).reshape(B * Tk, D), **t)
 
 
+@pytest.mark.parametrize("B,H,packed", [(1, 1, True), (41, 16, True), (43, 7, False), (192, 16, True)],
+                         ids=["1head", "656heads", "301heads_unpacked", "xl2_bench_3072heads"])
+def test_attention_p256_head_dim_72(B, H, packed, monkeypatch):
+    """T = 256, head dim 72 (DiT-XL/2): the persistent LDS-DMA kernels carry columns 64..71 as 8-column tails (compact
+    16-byte-row LDS images; a fifth k step of the score products, a third row tile of the transposed outputs).  Forward: the MFMA
+    sequence per output element is the one of the kernel in attention_mfma.hip (UWU_ATTN_P256F_D72=0) -> o and lse BIT FOR BIT.
+    Backward: delta = rowsum(dO * O) is summed in another order and rows 64..71 of dK^T / dV^T are accumulated per sub-tile, so
+    dq / dk / dv agree with the key-block + dq kernels (UWU_ATTN_P256_D72=0) to 2 bf16 ulps of the largest gradient, and with an
+    fp64 reference of the first heads as closely as those do.  Three launches each: the ring / prefetch pipeline must not depend
+    on timing; head counts with unequal shares per workgroup (656 = 2.6 per CU, 301) and the XL/2 bench's 3072."""
+    from uwudiff_amd import ops
+
+    T, d = 256, 72
+    D = H * d
+    g = torch.Generator(device="cuda").manual_seed(200 + B)
+    if packed:
+        qkv = torch.randn(B * T, 3 * D, device="cuda", generator=g).bfloat16()
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    else:
+        q, k, v = (torch.randn(B * T, D, device="cuda", generator=g).bfloat16() for _ in range(3))
+    do = (torch.randn(B * T, D, device="cuda", generator=g) * 0.5).bfloat16()
+    monkeypatch.setenv("UWU_ATTN_P256F", "1")  # the persistent forward at every head count (default: from 1024 heads)
+    outs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("UWU_ATTN_P256F_D72", flag)
+        monkeypatch.setenv("UWU_ATTN_P256_D72", flag)
+        for rep in range(3 if flag == "1" else 1):
+            o, lse = ops.attention_fwd(q, k, v, B, T, T, H, d)
+            if packed:  # (a gradient has the row stride of its tensor)
+                dqkv = torch.full_like(qkv, float("nan"))
+                dq, dk, dv = dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:]
+            else:
+                dq, dk, dv = (torch.full_like(q, float("nan")) for _ in range(3))
+            ops.attention_bwd(q, k, v, o, do, lse, dq, dk, dv, B, T, T, H, d)
+            cur = (o, lse, dq, dk, dv)
+            if flag == "1" and rep:
+                for a, b in zip(outs["1"], cur):
+                    assert torch.equal(a, b), "two launches of the persistent kernels differ"
+            outs[flag] = cur
+    assert torch.equal(outs["0"][0], outs["1"][0]) and torch.equal(outs["0"][1], outs["1"][1])
+    for a, b in zip(outs["0"][2:], outs["1"][2:]):
+        assert torch.isfinite(b.float()).all()
+        ulp = a.float().abs().max().item() * 2.0 ** -8
+        assert (a.float() - b.float()).abs().max().item() <= 2 * ulp
+    nb = min(B, 2)
+    qr, kr, vr = (t[: nb * T].double().reshape(nb, T, H, d).transpose(1, 2).detach().requires_grad_(True) for t in (q, k, v))
+    att = torch.softmax(qr @ kr.transpose(-1, -2) / math.sqrt(d), -1)
+    (att @ vr).backward(do[: nb * T].double().reshape(nb, T, H, d).transpose(1, 2))
+    for i, t in enumerate((qr, kr, vr)):
+        ref = t.grad.transpose(1, 2).reshape(nb * T, D)
+        e_old = (outs["0"][2 + i][: nb * T].double() - ref).abs().max().item()
+        e_new = (outs["1"][2 + i][: nb * T].double() - ref).abs().max().item()
+        assert e_new <= 1.25 * e_old + 1e-4, (i, e_new, e_old)
+
+
 @pytest.mark.parametrize("B,H,packed", [(1, 1, True), (100, 6, True), (43, 7, False), (768, 6, True)],
                          ids=["1head", "600heads", "301heads_unpacked", "bench_4608heads"])
 def test_attention_p256_kernels_are_bit_identical_to_the_per_head_kernels(B, H, packed, monkeypatch):

@@ -33,6 +33,7 @@ def main():
         for flag in ("0", "1"):
             setflag("UWU_ATTN_P256_D72", flag)
             setflag("UWU_ATTN_P256F_D72", flag)
+            setflag("UWU_ATTN_P256F", "1")  # (the forward at every head count, not only from 1024 heads)
             for rep in range(3 if flag == "1" else 1):
                 o, lse = ops.attention_fwd(q, k, v, B, T, T, H, d)
                 dqkv = torch.full_like(qkv, float("nan"))
@@ -58,6 +59,8 @@ def main():
             print(f"B={B} flag {flag}: max |dqkv - fp64| = {e:.3e}, max |o - fp64| = {eo:.3e}")
         fl = 4.0 * T * T * d * B * H
         res = {}
+        os.environ.pop("UWU_ATTN_P256F")
+        L.load().uwu_env_refresh()
         o, lse, dqkv = outs["1"]
         for rnd in range(3):
             for name, flag in (("fwd old", "0"), ("fwd p256", "1")):

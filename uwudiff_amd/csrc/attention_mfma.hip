@@ -878,7 +878,7 @@ extern "C" int uwu_attention_rope_bwd(const void* q, const void* k, const void* 
 }
 
 bool uwu_attn_p256_fwd_ok(int nheads, int T, int Tk, int d, int ldq, int ldk, int ldv, int ldo);
-int uwu_attn_p256_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int ldq, int ldk, int ldv,
+int uwu_attn_p256_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int d, int ldq, int ldk, int ldv,
                       int ldo, float scale, hipStream_t st);
 
 int uwu_attn_mfma_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* kbias, int B,
@@ -886,7 +886,7 @@ int uwu_attn_mfma_fwd(const void* q, const void* k, const void* v, void* o, floa
   UWU_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0,
                 "attention(mfma): q/k/v/o must be 16-byte aligned");
   if (!kbias && uwu_attn_p256_fwd_ok(B * H, T, Tk, d, ldq, ldk, ldv, ldo))
-    return uwu_attn_p256_fwd(q, k, v, o, lse, B, H, ldq, ldk, ldv, ldo, scale, st);
+    return uwu_attn_p256_fwd(q, k, v, o, lse, B, H, d, ldq, ldk, ldv, ldo, scale, st);
   MArgs a{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)o; a.lse = lse;
   a.kbias = kbias;

@@ -529,10 +529,24 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_p256(const PArgs a) {
 // drained the ring.  The kernel has NO load the compiler tracks; every wait is hand-counted (younger()).  O leaves through a
 // wave-private 4 KB LDS stage as whole 128-byte rows.  The arithmetic per output element is the sequence of the kernel in
 // attention_mfma.hip (bit-identical results).
-constexpr int F_RING = 5, F_SLOT = 16384;
-constexpr int F_OFF_O = F_RING * F_SLOT;      // 8 x 4 KB: per-wave O stage
-constexpr int F_OFF_Q = F_OFF_O + 8 * 4096;   // Q image [256 q][64 d] of the head in flight (then of the next one)
-constexpr int F_LDS = F_OFF_Q + 32768;        // 147456 B
+// Head dim 72: columns 64..71 travel as tails exactly as in the backward (compact 16-byte-row images: a tile's K / V tails as
+// [row >> 3][K 8 rows | V 8 rows] behind its tiles, the Q tail behind the Q image, a fifth k step of S^T against Q fragments whose
+// upper lane half is read from 16 zero bytes, a third row tile of O^T of which rows 64..71 = registers 0..3 are stored); the ring
+// is four slots there (three tiles ahead) to stay inside the 160 KB.
+template <int DH>
+struct FGeom {
+  static constexpr bool TAIL = DH > 64;
+  static constexpr int RING = TAIL ? 4 : 5;
+  static constexpr int SLOT = 16384 + (TAIL ? 2048 : 0);
+  static constexpr int OFF_TT = 16384;
+  static constexpr int OST = 4096 + (TAIL ? 512 : 0);           // per-wave O stage: [32 q][128 B] [+ [32 q][16 B]]
+  static constexpr int OFF_O = RING * SLOT;
+  static constexpr int OFF_Q = OFF_O + 8 * OST;                  // Q image [256 q][64 d] [+ tail [256 q][16 B]] of the head in flight
+  static constexpr int OFF_ZERO = OFF_Q + 32768 + (TAIL ? 4096 : 0);
+  static constexpr int LDS = OFF_ZERO + (TAIL ? 16 : 0);        // 147456 B (DH = 64), 147472 B (DH = 72)
+};
+static_assert(FGeom<64>::LDS == 147456 && FGeom<72>::LDS <= 163840, "LDS budget");
+constexpr int F_LDS = FGeom<64>::LDS;
 
 struct FArgs {
   const bf16_t *q, *k, *v;
@@ -546,9 +560,14 @@ template <int N>
 __device__ __forceinline__ void wait_vm_n() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-// wait until at most n (wave-uniform, 0 .. 15+) of this wave's vector-memory operations are in flight
+// wait until at most n (wave-uniform, 0 .. 20+) of this wave's vector-memory operations are in flight
 __device__ __forceinline__ void wait_vm(int n) {
-  switch (n < 15 ? n : 15) {
+  switch (n < 20 ? n : 20) {
+    case 20: wait_vm_n<20>(); break;
+    case 19: wait_vm_n<19>(); break;
+    case 18: wait_vm_n<18>(); break;
+    case 17: wait_vm_n<17>(); break;
+    case 16: wait_vm_n<16>(); break;
     case 15: wait_vm_n<15>(); break;
     case 14: wait_vm_n<14>(); break;
     case 13: wait_vm_n<13>(); break;
@@ -568,8 +587,14 @@ __device__ __forceinline__ void wait_vm(int n) {
   }
 }
 
+template <int DH>
 __global__ void __launch_bounds__(512, 2) attn_fwd_p256(const FArgs a) {
-  constexpr int T = 256, DH = 64;
+  using G = FGeom<DH>;
+  constexpr bool TAIL = G::TAIL;
+  constexpr int T = 256, NKS = TAIL ? 5 : 4, NDT = TAIL ? 3 : 2;
+  constexpr int F_RING = G::RING, AHEAD = F_RING - 1, F_SLOT = G::SLOT, F_OFF_O = G::OFF_O, F_OFF_Q = G::OFF_Q;
+  // vector-memory operations per wave: a tile (K, V [, tails]), a Q image (4 pieces [, tail]), a head's stores (4 O rows [, tail], lse)
+  constexpr int TILE_OPS = TAIL ? 3 : 2, Q_OPS = TAIL ? 5 : 4, ST_OPS = TAIL ? 6 : 5;
   char* const smem = p_smem;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -585,6 +610,8 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_p256(const FArgs a) {
   const unsigned QR0 = (unsigned)(F_OFF_Q + (q0 + r) * 128 + ((h ^ fsw(q0 + r)) << 4));  // chunk 2 s + h of query row q0 + r
   const int rowL = 4 * h + ((lane & 15) >> 2), chunkL = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);
   const unsigned A0 = (unsigned)(rowL * 128 + ((chunkL ^ fsw(rowL)) << 4) + 8 * (lane & 1));
+  const unsigned TQ0 = (unsigned)((r >> 3) * 256 + (r & 7) * 16);  // tails: row read of row r, transposing read (rows 4 h + q)
+  const unsigned TA0 = (unsigned)(rowL * 16 + 8 * (lane & 1));
   auto head_ptrs = [&](int j, int& b, int& hd) {
     const int bh = (int)blockIdx.x + j * (int)gridDim.x;
     b = bh / a.H;
@@ -608,58 +635,72 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_p256(const FArgs a) {
     const unsigned dst = smem_base + (unsigned)((g % F_RING) * F_SLOT + wave * 1024);
     glds16_s(kb_n, kvoff + (unsigned)(t64 * a.ldk * 2), dst);
     glds16_s(vb_n, vvoff + (unsigned)(t64 * a.ldv * 2), dst + 8192);
+    if constexpr (TAIL) {  // lanes 0-7: the K tail of rows 8 wave + lane, lanes 8-15: the V tail  (one more operation)
+      if (lane < 16) {
+        const int trow = t64 + 8 * wave + (lane & 7);
+        const bf16_t* src = lane < 8 ? kb_n + (int64_t)trow * a.ldk + 64 : vb_n + (int64_t)trow * a.ldv + 64;
+        glds16(src, smem_base + (unsigned)((g % F_RING) * F_SLOT + G::OFF_TT + wave * 256));
+      }
+    }
   };
   auto issue_q = [&]() {  // Q image of the issue head  (4 operations)
 #pragma unroll
     for (int p = 0; p < 4; ++p)
       glds16_s(qb_n, qvoff + (unsigned)(64 * p * a.ldq * 2), smem_base + (unsigned)(F_OFF_Q + p * 8192 + wave * 1024));
+    if constexpr (TAIL) {  // Q tail: wave w moves rows 32 w .. 32 w + 31  (one more operation)
+      if (lane < 32) glds16(qb_n + (int64_t)(32 * wave + lane) * a.ldq + 64, smem_base + (unsigned)(F_OFF_Q + 32768 + wave * 512));
+    }
   };
   // What a wave issues behind the DMA of tile i, inside iteration i's body: the next head's Q image (t == 1: 4 operations),
   // the head's O rows and lse (t == 3: 4 + 1 stores)
-  auto extras = [&](int i) { return ((i & 3) == 1 && (i >> 2) + 1 < nmy ? 4 : 0) + ((i & 3) == 3 ? 5 : 0); };
+  auto extras = [&](int i) { return ((i & 3) == 1 && (i >> 2) + 1 < nmy ? Q_OPS : 0) + ((i & 3) == 3 ? ST_OPS : 0); };
   // vector-memory operations of this wave that are YOUNGER than the DMA of tile g when iteration g begins: tile g's DMA was
   // issued in iteration g - (F_RING - 1) (or in the prologue, with the tiles behind it), everything since is in issue order
   auto younger = [&](int g) {
     int y = 0;
     const int gi = g - (F_RING - 1);  // issuing iteration
     if (gi < 0) {
-      for (int x = g + 1; x < F_RING - 1; ++x) y += x < total ? 2 : 0;  // the prologue's tiles behind it
+      for (int x = g + 1; x < F_RING - 1; ++x) y += x < total ? TILE_OPS : 0;  // the prologue's tiles behind it
     } else {
       y += extras(gi);
     }
-    for (int i = gi < 0 ? 0 : gi + 1; i < g; ++i) y += (i + F_RING - 1 < total ? 2 : 0) + extras(i);
+    for (int i = gi < 0 ? 0 : gi + 1; i < g; ++i) y += (i + F_RING - 1 < total ? TILE_OPS : 0) + extras(i);
     return y;
   };
   if (total == 0) return;
-  static_assert(F_RING - 1 == 4, "the tiles issued in iteration g belong to the head after the one being computed");
+  static_assert(AHEAD == 4 || AHEAD == 3, "the tile issued in iteration g belongs to the next head from t = 4 - AHEAD on");
+  if constexpr (TAIL)
+    if (tid < 4) reinterpret_cast<unsigned*>(smem + G::OFF_ZERO)[tid] = 0u;  // (published by the first tile's barrier)
   set_issue_head(0);
   head_ptrs(0, b_c, hd_c);
   issue_q();
 #pragma unroll
   for (int g = 0; g < F_RING - 1; ++g) issue_tile(g);  // (total >= 4)
 
-  uint4 qf[4];
-  f32x16 o[2];
+  uint4 qf[NKS];
+  f32x16 o[NDT];
   float m = -INFINITY, l = 0.f;
   for (int g = 0; g < total; ++g) {
     const int j = g >> 2, t = g & 3;
     int n_fly = younger(g);  // tile g has landed when at most this many operations are in flight
     if (t == 0 && j > 0) {   // ... and the head's Q image, issued one iteration AFTER its first tile (in iteration g - 3, behind
       // that iteration's tile): younger than it are the tiles of iterations g - 2 and g - 1 and the previous head's 5 stores
-      const int yq = (g - 2 + F_RING - 1 < total ? 2 : 0) + (g - 1 + F_RING - 1 < total ? 2 : 0) + 5;
+      const int yq = (g - 2 + F_RING - 1 < total ? TILE_OPS : 0) + (g - 1 + F_RING - 1 < total ? TILE_OPS : 0) + ST_OPS;
       n_fly = yq < n_fly ? yq : n_fly;
     }
     wait_vm(n_fly);
     __builtin_amdgcn_s_barrier();  // ... everybody's pieces; everybody has finished reading tile g - 1
-    if (t == 0) {
-      head_ptrs(j, b_c, hd_c);
-      if (j + 1 < nmy) set_issue_head(j + 1);  // tiles g + 4 .. g + 7 and the Q image issued at t == 1 are the next head's
-    }
+    if (t == 0) head_ptrs(j, b_c, hd_c);
+    // the tiles issued from t = 4 - AHEAD on and the Q image issued at t == 1 are the next head's
+    if (t == 4 - AHEAD && j + 1 < nmy) set_issue_head(j + 1);
     if (g + F_RING - 1 < total) issue_tile(g + F_RING - 1);  // into tile g - 1's slot
     if (t == 0) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const uint4*>(smem + (QR0 ^ (unsigned)(s << 5)));
-      o[0] = o[1] = f32x16{};
+      if constexpr (TAIL)  // k slots 8-15 of the fifth step (the upper lane half): zeros
+        qf[4] = *reinterpret_cast<const uint4*>(smem + (h ? (unsigned)G::OFF_ZERO : (unsigned)(F_OFF_Q + 32768 + (q0 + r) * 16)));
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) o[dt] = f32x16{};
       m = -INFINITY;
       l = 0.f;
     }
@@ -673,6 +714,10 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_p256(const FArgs a) {
       for (int ss = 0; ss < 4; ++ss) {
         const uint4 kfr = *reinterpret_cast<const uint4*>(smem + Ks + (B0 ^ (unsigned)(ss << 5)) + 4096u * kt);
         s[kt] = mfma32(kfr, qf[ss], s[kt]);
+      }
+      if constexpr (TAIL) {
+        const uint4 kfr = *reinterpret_cast<const uint4*>(smem + Ks + (unsigned)G::OFF_TT + TQ0 + 1024u * kt);
+        s[kt] = mfma32(kfr, qf[4], s[kt]);
       }
     }
     float mx = s[0][0];
@@ -703,6 +748,10 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_p256(const FArgs a) {
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+    if constexpr (TAIL) {  // rows 64..71 are registers 0..3 of the third tile; the rest of it is never stored
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[2][i] *= alpha;
+    }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -714,6 +763,10 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_p256(const FArgs a) {
           const uint4 vt = tr_pair(Vs + x0, Vs + (x0 ^ 0x20u) + 1024u);
           o[dt] = mfma32(vt, pf, o[dt]);
         }
+        if constexpr (TAIL) {
+          const unsigned x0 = Ks + (unsigned)G::OFF_TT + 128u + TA0 + 512u * s2 + 1024u * kt;
+          o[2] = mfma32(tr_pair(x0, x0 + 256u), pf, o[2]);
+        }
       }
     if (t == 3) {  // the head is complete: O / l through the wave's LDS stage as whole rows, lse  (4 + 1 stores: extras())
       const int b = b_c, hd = hd_c;
@@ -724,7 +777,7 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_p256(const FArgs a) {
         lt = lo + hi;
       }
       const float inv = 1.f / lt;
-      char* mine = smem + F_OFF_O + wave * 4096;
+      char* mine = smem + F_OFF_O + wave * G::OST;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -739,6 +792,11 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_p256(const FArgs a) {
         const int row = 8 * p + (lane >> 3), ch = lane & 7;
         const uint4 x = *reinterpret_cast<const uint4*>(mine + row * 128 + ((ch ^ (row & 7)) << 4));
         *reinterpret_cast<uint4*>(ob + (int64_t)row * a.ldo + 8 * ch) = x;
+      }
+      if constexpr (TAIL) {  // (lanes 32-63 repeat lanes 0-31: one store instruction, the same bytes to the same addresses)
+        store4(reinterpret_cast<bf16_t*>(mine + 4096 + r * 16 + 8 * h), f32x4{o[2][0] * inv, o[2][1] * inv, o[2][2] * inv, o[2][3] * inv});
+        const uint4 xt = *reinterpret_cast<const uint4*>(mine + 4096 + r * 16);
+        *reinterpret_cast<uint4*>(ob + (int64_t)r * a.ldo + 64) = xt;
       }
       // (every lane stores: lanes r and r + 32 write the same value to the same address -- one store INSTRUCTION either way,
       // which is what the hand-counted waits count)
@@ -810,23 +868,28 @@ bool uwu_attn_p256_fwd_ok(int nheads, int T, int Tk, int d, int ldq, int ldk, in
   // against 16.0 for the two-workgroups-per-head kernel) and the lack of a second workgroup per CU cost more than the
   // streaming gains (768 heads: 28.6 vs 27.0 us; 4608: 155 vs 160).  The backward wins at every size (96 heads: 19 vs 23 us).
   if (!on.is('1') && nheads < 1024) return false;
-  return T == 256 && Tk == 256 && d == 64 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && uwu_dev_lds_fits(F_LDS) &&
-         uwu_dev_cus() > 0;
+  if (T != 256 || Tk != 256 || ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8 || uwu_dev_cus() <= 0) return false;
+  if (d == 64) return uwu_dev_lds_fits(F_LDS);
+  static UwuEnv on72("UWU_ATTN_P256F_D72");  // "0": head dim 72 stays on the kernel of attention_mfma.hip
+  return d == 72 && !on72.get().is('0') && uwu_dev_lds_fits(FGeom<72>::LDS);
 }
 
-int uwu_attn_p256_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int ldq, int ldk, int ldv,
+int uwu_attn_p256_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int d, int ldq, int ldk, int ldv,
                       int ldo, float scale, hipStream_t st) {
-  static unsigned char done[UWU_MAX_DEV];
+  static unsigned char done[2][UWU_MAX_DEV];
   const int n_cu = uwu_dev_cus();
-  if (n_cu <= 0 || !uwu_func_lds(reinterpret_cast<const void*>(attn_fwd_p256), F_LDS, done)) {
-    uwu_set_error("attention_fwd(p256): the device cannot give a workgroup %d bytes of LDS", (int)F_LDS);
+  const int lds = d == 72 ? FGeom<72>::LDS : F_LDS;
+  const void* fn = d == 72 ? reinterpret_cast<const void*>(attn_fwd_p256<72>) : reinterpret_cast<const void*>(attn_fwd_p256<64>);
+  if (n_cu <= 0 || !uwu_func_lds(fn, lds, done[d == 72])) {
+    uwu_set_error("attention_fwd(p256): the device cannot give a workgroup %d bytes of LDS", lds);
     return UWU_ELAUNCH;
   }
   FArgs a{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)o; a.lse = lse;
   a.B = B; a.H = H; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.nheads = B * H; a.scale = scale;
   const int grid = a.nheads < n_cu ? a.nheads : n_cu;
-  hipLaunchKernelGGL(attn_fwd_p256, dim3(grid), dim3(512), F_LDS, st, a);
+  if (d == 72) hipLaunchKernelGGL(attn_fwd_p256<72>, dim3(grid), dim3(512), lds, st, a);
+  else hipLaunchKernelGGL(attn_fwd_p256<64>, dim3(grid), dim3(512), lds, st, a);
   UWU_LAUNCH_CHECK("attention_fwd(p256)");
   return UWU_OK;
 }

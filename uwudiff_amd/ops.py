@@ -91,6 +91,9 @@ def attention_fwd(q, k, v, B, Tq, Tk, H, d, scale=None, key_bias=None):
 
 def attention_bwd(q, k, v, o, do, lse, dq, dk, dv, B, Tq, Tk, H, d, scale=None, key_bias=None):
     scale = scale if scale is not None else d ** -0.5
+    # the C ABI has one leading dimension per (tensor, gradient) pair: a gradient laid out differently would be written out of bounds
+    if (dq.stride(0), dk.stride(0), dv.stride(0), do.stride(0)) != (q.stride(0), k.stride(0), v.stride(0), o.stride(0)):
+        raise ValueError("attention_bwd: dq / dk / dv / do must have the row strides of q / k / v / o")
     delta = torch.empty_like(lse)
     tail = (L.ptr(o), L.ptr(do), L.ptr(lse), L.ptr(delta), _p(dq), _p(dk), _p(dv), B, Tq, Tk, H, d, q.stride(0),
             k.stride(0), v.stride(0), o.stride(0), scale, L.dt(q), L.stream())
