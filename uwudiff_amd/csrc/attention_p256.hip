@@ -53,6 +53,7 @@ struct PArgs {
   const float* lse;
   int B, H, ldq, ldk, ldv, ldo, nheads;
   float scale;
+  int prio;  // UWU_P256_PRIO (A/B): 1 = waves 4-7 run at s_setprio 1, 2 = waves 0-3
 };
 
 // 16-byte chunk swizzle of the 128-byte-row images (Q / dO tiles, K image): bit0 = r2 ^ r4, bit1 = r3 ^ r4, bit2 = r1
@@ -342,6 +343,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_p256(const PArgs a) {
 
   // ---- prologue: head 0's K image / lse / fragments and tile 0, then tile 1 behind the first delta
   if (total == 0) return;
+  if ((a.prio == 1 && wave >= 4) || (a.prio == 2 && wave < 4)) __builtin_amdgcn_s_setprio(1);
   if constexpr (TAIL)
     if (tid < 4) reinterpret_cast<unsigned*>(smem + G::OFF_ZERO)[tid] = 0u;  // (the prologue's barrier publishes it)
   issue_head(0);
@@ -554,6 +556,7 @@ struct FArgs {
   float* lse;
   int B, H, ldq, ldk, ldv, ldo, nheads;
   float scale;
+  int prio;
 };
 
 template <int N>
@@ -668,6 +671,7 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_p256(const FArgs a) {
     return y;
   };
   if (total == 0) return;
+  if ((a.prio == 1 && wave >= 4) || (a.prio == 2 && wave < 4)) __builtin_amdgcn_s_setprio(1);
   static_assert(AHEAD == 4 || AHEAD == 3, "the tile issued in iteration g belongs to the next head from t = 4 - AHEAD on");
   if constexpr (TAIL)
     if (tid < 4) reinterpret_cast<unsigned*>(smem + G::OFF_ZERO)[tid] = 0u;  // (published by the first tile's barrier)
@@ -807,6 +811,11 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_p256(const FArgs a) {
 
 }  // namespace
 
+static int p256_prio() {
+  static UwuEnv e("UWU_P256_PRIO");
+  return e.get().set ? e.ival : 0;
+}
+
 bool uwu_attn_p256_ok(int T, int Tk, int d, int ldq, int ldk, int ldv, int ldo) {
   static UwuEnv on("UWU_ATTN_P256");  // "0": the one-workgroup-per-head kernel of attention_mfma.hip (A/B comparisons)
   // (a device that cannot give one workgroup P_LDS bytes falls through to the per-head kernels of attention_mfma.hip)
@@ -830,6 +839,7 @@ int uwu_attn_p256_bwd(const void* q, const void* k, const void* v, const void* o
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o; a.dO = (const bf16_t*)dO;
     a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.lse = lse;
     a.B = B; a.H = H; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.nheads = B * H; a.scale = scale;
+    a.prio = p256_prio();
     const int grid = a.nheads < n_cu ? a.nheads : n_cu;
     hipLaunchKernelGGL((attn_bwd_p256<0, 72>), dim3(grid), dim3(512), PGeom<72>::LDS, st, a);
     UWU_LAUNCH_CHECK("attention_bwd(p256, d = 72)");
@@ -847,6 +857,7 @@ int uwu_attn_p256_bwd(const void* q, const void* k, const void* v, const void* o
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (const bf16_t*)o; a.dO = (const bf16_t*)dO;
   a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.lse = lse;
   a.B = B; a.H = H; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.nheads = B * H; a.scale = scale;
+  a.prio = p256_prio();
   // one workgroup per CU (150 KB of LDS each); every workgroup exits after its last head -- no inter-workgroup waits
   const int grid = a.nheads < n_cu ? a.nheads : n_cu;
   static UwuEnv abl("UWU_P256_ABL");  // timing-only ablations / stamps (tools/bench_attn.py); results are wrong with them
@@ -887,6 +898,7 @@ int uwu_attn_p256_fwd(const void* q, const void* k, const void* v, void* o, floa
   FArgs a{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.out = (bf16_t*)o; a.lse = lse;
   a.B = B; a.H = H; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.nheads = B * H; a.scale = scale;
+  a.prio = p256_prio();
   const int grid = a.nheads < n_cu ? a.nheads : n_cu;
   if (d == 72) hipLaunchKernelGGL(attn_fwd_p256<72>, dim3(grid), dim3(512), lds, st, a);
   else hipLaunchKernelGGL(attn_fwd_p256<64>, dim3(grid), dim3(512), lds, st, a);

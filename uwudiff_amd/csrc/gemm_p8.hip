@@ -477,7 +477,8 @@ bool uwu_gemm_p8_ok(const GemmArgs& g, bool tb) {
   if (on.is('1')) return true;
   // dGELU: its epilogue loads keep a tile from streaming into the next (every tile drains): in the step the 256 x 256 two-stage
   // kernel is faster (DiT-B/2 fc2 input gradient: 697 vs 668 TFLOP/s)
-  if (g.epi == UWU_EPI_DGELU) return false;
+  static UwuEnv dg("UWU_P8_DGELU");  // "1": try it anyway (A/B)
+  if (g.epi == UWU_EPI_DGELU && !dg.get().is('1')) return false;
   const int kmin = kmin_e.get().set ? kmin_e.ival : 512;
   const int64_t tiles = (int64_t)((g.M + 255) / 256) * ((g.N + 255) / 256);
   // padded column tiles: at most 1/8 of the columns may be padding (N = 1152 -> 5 tiles of 256: 10 %)
