@@ -115,7 +115,7 @@ def main_dit(steps=60, dtype="bf16", lr=1e-4, B=16, out=None, preset="DiT-S/2", 
     return rows, dev
 
 
-def main_unet_sdxl_width(steps=6, dtype="bf16", lr=1e-4, B=1, out=None):
+def main_unet_sdxl_width(steps=6, dtype="bf16", lr=1e-4, B=1, out=None, latent=32):
     """The overlay on the SDXL-WIDTH UNet (BASELINE config 4's widths 320 / 640 / 1280, heads 5 / 10 / 20, 77 x 2048 context,
     text_time conditioning; transformer depth cut to 1 / 2 / 2 as in tests/test_configs_gpu.py) at 4x32x32 latents: per-step loss
     of the HIP path against the fp32 CPU oracle (oracle/unet.py) under AdamW from the same weights and injected draws."""
@@ -127,7 +127,7 @@ def main_unet_sdxl_width(steps=6, dtype="bf16", lr=1e-4, B=1, out=None):
     lf = DiffusionLoss(EulerDiscreteScheduler.from_pretrained("sdxl"))
     osch = OSched.sdxl()
     g = torch.Generator().manual_seed(11)
-    data = torch.randn(8, 4, 32, 32, generator=g)
+    data = torch.randn(8, 4, latent, latent, generator=g)
     ctx, pooled = torch.randn(B, 77, 2048, generator=g) * 0.5, torch.randn(B, 1280, generator=g) * 0.5
     ids = torch.tensor([[1024.0, 1024, 0, 0, 1024, 1024]] * B)
     cond = dict(encoder_hidden_states=ctx, added_cond_kwargs={"text_embeds": pooled, "time_ids": ids})
@@ -135,7 +135,7 @@ def main_unet_sdxl_width(steps=6, dtype="bf16", lr=1e-4, B=1, out=None):
     rows = []
     for step in range(steps):
         x = data[(step * B) % 7:(step * B) % 7 + B]
-        noise = torch.randn(B, 4, 32, 32, generator=g)
+        noise = torch.randn(B, 4, latent, latent, generator=g)
         t = torch.randint(0, 1000, (B,), generator=g)
         o = OL.diffusion_loss(osch, x, noise, t, lambda n, tt: ora(n, tt, **cond)[0])
         oopt.zero_grad()

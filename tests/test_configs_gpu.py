@@ -106,7 +106,18 @@ def unet_models(dtype, seed=0, with_oracle=True):
     from uwudiff_amd.unet import UNet2DConditionModel
 
     torch.manual_seed(seed)
-    ora = UNetOracle(**SDXL_CUT)
+    # (every parameter is overwritten just below: the modules' own initialisers -- 40 s of the suite for 0.9 B parameters -- are
+    # switched off while the oracle is built)
+    import torch.nn.init as I
+
+    saved = {n: getattr(I, n) for n in ("kaiming_uniform_", "uniform_", "normal_", "xavier_uniform_", "trunc_normal_")}
+    try:
+        for n in saved:
+            setattr(I, n, lambda t, *a, **k: t)
+        ora = UNetOracle(**SDXL_CUT)
+    finally:
+        for n, f in saved.items():
+            setattr(I, n, f)
     with torch.no_grad():  # away from the near-zero init so every branch carries signal
         for n, p in ora.named_parameters():
             if p.dim() > 1:

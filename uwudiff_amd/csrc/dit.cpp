@@ -591,15 +591,23 @@ extern "C" int uwu_dit_forward(const uwu_dit_desc* dp, const float* noisy, const
   const F8 f8{d.fp8, d.f8_scale, d.f8_amax, d.f8_fmt, P.at<char>(L.x8), nullptr, P.at<char>(L.dy8),
               P.at<char>(L.dy8t), P.at<char>(L.wsc), P.at<char>(L.w8), L.wsc_bytes, L.w8_layer, d.D, st};
   if (d.fp8) {
-    if (d.fp8 == 2)  // delayed scaling: the scales of this step come from the amax values recorded during the last one
-      RUN(uwu_fp8_update_scales(d.f8_amax, d.f8_scale, d.f8_fmt, 12 * d.L, 1.f, st));
-    const F8 fw{1, d.f8_scale, d.f8_amax, d.f8_fmt, nullptr, nullptr, nullptr, nullptr, nullptr, f8.w8, 0, L.w8_layer, d.D, st};
+    // weights always scale just in time: every weight's amax pass first, then ONE scale update for all 12 L roles -- under
+    // delayed scaling the same launch turns the activations' amax values of the last step into this step's scales (just-in-time
+    // mode: their amax slots are zero here and their scales stay) --, then the quantising passes with those scales
+    const F8 fw{2, d.f8_scale, d.f8_amax, d.f8_fmt, nullptr, nullptr, nullptr, nullptr, nullptr, f8.w8, 0, L.w8_layer, d.D, st};
+    const int rows[4] = {D3, D, D4, D}, cols[4] = {D, D, D, D4};
     for (int l = 0; l < d.L; ++l) {
       const LayerW w = layer_weights(d, l);
       const void* ws4[4] = {w.qkv_w, w.o_w, w.fc1_w, w.fc2_w};
-      const int rows[4] = {D3, D, D4, D}, cols[4] = {D, D, D, D4};
-      for (int i = 0; i < 4; ++i)  // weights always scale just in time (two small passes)
-        RUN(fw.quant(ws4[i], UWU_BF16, rows[i], cols[i], fw.role(l, 8 + i), fw.w(l, i, false), fw.w(l, i, true), nullptr, false));
+      for (int i = 0; i < 4; ++i)
+        RUN(uwu_fp8_amax(ws4[i], UWU_BF16, (int64_t)rows[i] * cols[i], d.f8_amax + fw.role(l, 8 + i), st));
+    }
+    RUN(uwu_fp8_update_scales(d.f8_amax, d.f8_scale, d.f8_fmt, 12 * d.L, 1.f, st));
+    for (int l = 0; l < d.L; ++l) {
+      const LayerW w = layer_weights(d, l);
+      const void* ws4[4] = {w.qkv_w, w.o_w, w.fc1_w, w.fc2_w};
+      for (int i = 0; i < 4; ++i)
+        RUN(fw.quant(ws4[i], UWU_BF16, rows[i], cols[i], fw.role(l, 8 + i), fw.w(l, i, false), fw.w(l, i, true), nullptr, true));
     }
   }
 
