@@ -449,7 +449,7 @@ def run_secondary(steps=5, warmup=2):
     return out
 
 
-GEMM_SOURCES = ("gemm_shared.h", "gemm.hip", "gemm_p8.hip", "gemm_p8n.hip")  # (tools/summarize_pmc.py hashes the same list)
+GEMM_SOURCES = ("gemm_shared.h", "gemm.hip", "gemm_p8.hip", "gemm_p8n.hip", "gemm_p8f.hip")  # (tools/summarize_pmc.py hashes the same list)
 
 
 def src_sha16():

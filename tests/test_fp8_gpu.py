@@ -79,6 +79,75 @@ def test_gemm_fp8_exact_on_integers(fmt_a, M, N, K):
     assert torch.equal(c.float().cpu(), want.bfloat16().float())
 
 
+@pytest.mark.parametrize("fmt_a", [0, 1])
+@pytest.mark.parametrize("M,N,K,bias", [(256, 256, 512, False), (300, 264, 768, True), (1024, 1152, 1152 + 128, True),
+                                        (2048 + 40, 1152, 4608, False), (49152, 1152, 1152 + 128, True)],
+                         ids=["one_tile", "ragged", "xl_width_10steps", "ragged_rows_36steps", "xl2_bench_rows"])
+def test_gemm_p8f_exact_on_integers_and_equal_to_the_two_stage_kernel(fmt_a, M, N, K, bias, monkeypatch):
+    """The 8-phase fp8 kernel (gemm_p8f.hip; UWU_GEMM_P8F=1 forces it for every shape it can run: K a multiple of 256, >= 512):
+    persistent workgroups, the element stream running on across tile boundaries, quadrant epilogues inside the next tile's first
+    K step.  Exact on integer operands for both operand formats, ragged M / N, with and without bias, one tile per workgroup up to
+    960 tiles on 256 workgroups -- and bit-identical to gemm_f8_kernel (UWU_GEMM_P8F=0) on random operands (same MFMA, same k
+    order per accumulator, same epilogue)."""
+    from uwudiff_amd import lib as L
+    from uwudiff_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N + fmt_a)
+    a = torch.randint(-3, 4, (M, K), generator=g, device="cuda").float()
+    b = torch.randint(-2, 3, (N, K), generator=g, device="cuda").float()
+    a[:, ::7] = 0
+    b[::5] = 1.0
+    bv = torch.randint(-4, 5, (N,), generator=g, device="cuda").float() if bias else None
+    sa, sb = torch.tensor([2.0], device="cuda"), torch.tensor([0.5], device="cuda")
+    a8, _ = ops.fp8_quantize(a, sa, fmt_a)
+    b8, _ = ops.fp8_quantize(b, sb, 0)
+    epi = L.EPI_BIAS if bias else L.EPI_NONE
+    monkeypatch.setenv("UWU_GEMM_P8F", "1")
+    c = ops.gemm_fp8(a8, b8, sa, sb, fmt_a=fmt_a, bias=bv, epilogue=epi)
+    c_again = ops.gemm_fp8(a8, b8, sa, sb, fmt_a=fmt_a, bias=bv, epilogue=epi)
+    want = a @ b.t() + (bv if bias else 0)
+    assert torch.equal(c.float(), want.bfloat16().float())
+    assert torch.equal(c, c_again)
+    # random fp8 bytes (finite values only): bit-identical to the two-stage kernel
+    ra = torch.randint(0, 120, (M, K), generator=g, device="cuda", dtype=torch.uint8) | (torch.randint(0, 2, (M, K), generator=g, device="cuda", dtype=torch.uint8) << 7)
+    rb = torch.randint(0, 120, (N, K), generator=g, device="cuda", dtype=torch.uint8) | (torch.randint(0, 2, (N, K), generator=g, device="cuda", dtype=torch.uint8) << 7)
+    s1, s2 = torch.tensor([37.0], device="cuda"), torch.tensor([3.0], device="cuda")
+    new = ops.gemm_fp8(ra, rb, s1, s2, fmt_a=fmt_a, bias=bv, epilogue=epi)
+    monkeypatch.setenv("UWU_GEMM_P8F", "0")
+    old = ops.gemm_fp8(ra, rb, s1, s2, fmt_a=fmt_a, bias=bv, epilogue=epi)
+    assert torch.isfinite(new.float()).all() and torch.equal(new, old)
+
+
+@pytest.mark.parametrize("fmt_a", [0, 1])
+@pytest.mark.parametrize("No,Ki,M", [(1152, 1152, 8192), (4608, 1152, 4096 + 2048), (1152 + 8, 384, 16384), (3456, 1152, 49152)],
+                         ids=["25tiles", "90tiles_48steps", "ragged", "xl2_qkv"])
+def test_gemm_p8f_weight_gradient_slices(fmt_a, No, Ki, M, monkeypatch):
+    """Weight gradient on the 8-phase kernel: (K slice, tile) units, fp32 partial slabs, splitk reduce.  Exact on integers (the
+    partial sums and their sum are integers below 2^24) and accumulating into a non-zero dW; against the two-stage kernel's
+    result to fp32 summation order on random operands."""
+    from uwudiff_amd import lib as L
+    from uwudiff_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(No + Ki + fmt_a)
+    dyt = torch.randint(-3, 4, (No, M), generator=g, device="cuda").float()
+    xt = torch.randint(-2, 3, (Ki, M), generator=g, device="cuda").float()
+    sa, sb = torch.tensor([2.0], device="cuda"), torch.tensor([0.5], device="cuda")
+    a8, _ = ops.fp8_quantize(dyt, sa, fmt_a)
+    b8, _ = ops.fp8_quantize(xt, sb, 0)
+    dw0 = torch.randint(-5, 6, (No, Ki), generator=g, device="cuda").float()
+    monkeypatch.setenv("UWU_GEMM_P8F_PART", "1")
+    dw = dw0.clone()
+    ops.gemm_fp8(a8, b8, sa, sb, fmt_a=fmt_a, epilogue=L.EPI_ACCUM, out=dw)
+    assert torch.equal(dw, dw0 + dyt @ xt.t())
+    ra = torch.randint(0, 120, (No, M), generator=g, device="cuda", dtype=torch.uint8)
+    rb = torch.randint(0, 120, (Ki, M), generator=g, device="cuda", dtype=torch.uint8)
+    s1, s2 = torch.tensor([4096.0], device="cuda"), torch.tensor([64.0], device="cuda")
+    new = ops.gemm_fp8(ra, rb, s1, s2, fmt_a=fmt_a, epilogue=L.EPI_ACCUM, out=torch.zeros(No, Ki, device="cuda"))
+    monkeypatch.setenv("UWU_GEMM_P8F_PART", "0")
+    old = ops.gemm_fp8(ra, rb, s1, s2, fmt_a=fmt_a, epilogue=L.EPI_ACCUM, out=torch.zeros(No, Ki, device="cuda"))
+    torch.testing.assert_close(new, old, rtol=1e-5, atol=1e-5 * float(old.abs().max()))
+
+
 @pytest.mark.parametrize("epi", ["none", "bias", "bias_gelu", "dgelu"])
 def test_gemm_fp8_random_with_epilogues(epi):
     from uwudiff_amd import lib as L

@@ -34,7 +34,7 @@ fetch, nf, pf = load(sys.argv[1], "FETCH_SIZE")
 write, nw, pw = load(sys.argv[2], "WRITE_SIZE")
 _csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "uwudiff_amd", "csrc")
 _h = hashlib.sha256()
-for _name in ("gemm_shared.h", "gemm.hip", "gemm_p8.hip", "gemm_p8n.hip"):  # = bench.py GEMM_SOURCES
+for _name in ("gemm_shared.h", "gemm.hip", "gemm_p8.hip", "gemm_p8n.hip", "gemm_p8f.hip"):  # = bench.py GEMM_SOURCES
     _h.update(open(os.path.join(_csrc, _name), "rb").read())
 out = {
     "gemm_src_sha16": _h.hexdigest()[:16],  # bench.py reports the number only for these sources

@@ -2225,7 +2225,8 @@ extern "C" int uwu_conv3x3_wgrad(const void* dy, const void* x, float* dw, float
 extern "C" size_t uwu_gemm_fp8_scratch_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K < 128) return 0;
   const int tiles = ((M + 255) / 256) * ((N + 255) / 256);
-  return (size_t)f8_split(tiles, K / 128) * M * N * sizeof(float);
+  const int a = f8_split(tiles, K / 128), b = K % 128 ? 0 : uwu_gemm_p8f_split(tiles, K / 128);  // (either kernel may take it)
+  return (size_t)(a > b ? a : b) * M * N * sizeof(float);
 }
 
 extern "C" int uwu_gemm_fp8(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux, int M,
@@ -2245,6 +2246,14 @@ extern "C" int uwu_gemm_fp8(const void* A, const void* B, void* C, void* C2, con
     UWU_CHECK_ARG(N % 4 == 0 && ldc % 4 == 0 && ldc >= N && ((uintptr_t)C & 15) == 0, "gemm_fp8: ACCUM needs 16-byte rows in C");
     UWU_CHECK_ARG(scratch && ((uintptr_t)scratch & 15) == 0 && scratch_bytes >= uwu_gemm_fp8_scratch_bytes(M, N, K),
                   "gemm_fp8: ACCUM needs uwu_gemm_fp8_scratch_bytes(M, N, K) of scratch");
+    if (uwu_gemm_p8f_part_ok(g)) {  // the 8-phase kernel over (K slice, tile) units, then the same reduce
+      UwuProfScope prof(stream);
+      RETURN_IF(uwu_launch_gemm_p8f_part(g, fmt_a == UWU_FP8_E5M2, scale_a, scale_b, scratch, st));
+      launch_splitk_reduce(static_cast<const float*>(scratch), static_cast<float*>(C), M, N, ldc, g.wide, st);
+      prof.done(UWU_PROF_GEMM_WGRAD, 0, 2.0 * M * N * K, ((double)M * K + (double)N * K) + (double)M * N * 4);
+      UWU_LAUNCH_CHECK("gemm_p8f(split-K)");
+      return UWU_OK;
+    }
     return fmt_a == UWU_FP8_E5M2 ? launch_f8_part<1>(g, scale_a, scale_b, scratch, st)
                                  : launch_f8_part<0>(g, scale_a, scale_b, scratch, st);
   }
@@ -2255,6 +2264,12 @@ extern "C" int uwu_gemm_fp8(const void* A, const void* B, void* C, void* C2, con
   if (epilogue == UWU_EPI_BIAS_GELU) UWU_CHECK_ARG(C2 && ((uintptr_t)C2 & 15) == 0, "gemm_fp8: C2 missing/misaligned");
   if (epilogue == UWU_EPI_DGELU)
     UWU_CHECK_ARG(aux && ldaux % 4 == 0 && ldaux >= N && ((uintptr_t)aux & 7) == 0, "gemm_fp8: aux missing/misaligned");
+  if (uwu_gemm_p8f_ok(g)) {
+    UwuProfScope prof(stream);
+    RETURN_IF(uwu_launch_gemm_p8f(g, fmt_a == UWU_FP8_E5M2, scale_a, scale_b, st));
+    prof.done(gemm_tag(g, false, false), 0, 2.0 * M * N * K, gemm_bytes(g, 1, 2));
+    return UWU_OK;
+  }
 #define F8_CASE(E)                                                                   \
   case E:                                                                            \
     return fmt_a == UWU_FP8_E5M2 ? launch_f8<E, 1>(g, scale_a, scale_b, st) : launch_f8<E, 0>(g, scale_a, scale_b, st);

@@ -433,7 +433,7 @@ __global__ void __launch_bounds__(512, 2) gemm_p8_kernel(const GemmArgs g) {
 
 // workgroups of the persistent grid: one per CU of the current device (a multiple of 8, so that a workgroup's tiles stay on
 // one XCD chunk); UWU_P8_GRID=n overrides (sweeps)
-int p8_cus() {
+int p8_cus_impl() {
   static UwuEnv ge("UWU_P8_GRID");
   if (ge.get().set && ge.ival >= 8) return ge.ival & ~7;
   const int cus = uwu_dev_cus();
@@ -450,7 +450,7 @@ int launch_p8(GemmArgs g, hipStream_t st) {
   }
   g.tiles_m = (g.M + 255) / 256;
   g.tiles_n = (g.N + 255) / 256;
-  const int nblk = g.tiles_m * g.tiles_n, ncu = p8_cus();
+  const int nblk = g.tiles_m * g.tiles_n, ncu = p8_cus_impl();
   {
     static UwuEnv ce("UWU_P8_CONT");
     g.p8_cont = ce.get().is('0') ? 0 : 1;
@@ -463,6 +463,8 @@ int launch_p8(GemmArgs g, hipStream_t st) {
 }
 
 }  // namespace
+
+int uwu_p8_cus() { return p8_cus_impl(); }
 
 // bf16 in / bf16 out, K a multiple of 64, 16-byte addressable operands.  UWU_GEMM_P8=0: off, =1: every shape it can run
 // (tests, A/B comparisons); default: K >= 512 and at least one tile per CU.

@@ -462,3 +462,9 @@ bool uwu_gemm_p8_ok(const GemmArgs& g, bool tb);
 // its 128 x 384 sibling (gemm_p8n.hip): N a multiple of 384
 int uwu_launch_gemm_p8n(const GemmArgs& g, bool tb, hipStream_t st);
 bool uwu_gemm_p8n_ok(const GemmArgs& g, bool tb);
+// the 8-phase kernel on fp8 operands (gemm_p8f.hip): forward / input gradient, and the weight gradient's K slices
+bool uwu_gemm_p8f_ok(const GemmArgs& g);
+int uwu_launch_gemm_p8f(GemmArgs g, int fmt_a, const float* sa, const float* sb, hipStream_t st);
+int uwu_gemm_p8f_split(int tiles, int steps);
+bool uwu_gemm_p8f_part_ok(const GemmArgs& g);
+int uwu_launch_gemm_p8f_part(GemmArgs& g, int fmt_a, const float* sa, const float* sb, void* scratch, hipStream_t st);
