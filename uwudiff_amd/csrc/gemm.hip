@@ -1371,7 +1371,9 @@ __device__ __forceinline__ unsigned f8_pack4(const f32x4& v, float s) {
   return (unsigned)r;
 }
 
-template <int EPI>
+// FULL: the tile has no row / column past M / N (a wave-uniform fact) -- the per-element masks of the ragged form (a v_cndmask per
+// element and output, ~8 % of this epilogue's VALU) are compiled out.
+template <int EPI, bool FULL = false>
 __device__ __forceinline__ void f8_emit_epilogue(f32x4 (&acc)[8][4], const GemmArgs& g, char* smem, int m0, int n0, int tid) {
   constexpr int FMT = EPI == UWU_EPI_DGELU ? 1 : 0;
   constexpr int QP = F8Q_PITCH;
@@ -1397,6 +1399,7 @@ __device__ __forceinline__ void f8_emit_epilogue(f32x4 (&acc)[8][4], const GemmA
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = n_w + 16 * j + 4 * fq;
+      // (predicated in the FULL form too: unconditional, hipcc hoisted the aux loads of all eight rows and spilled 42 registers)
       dst[j] = (m < g.M && n < g.N) ? *reinterpret_cast<const uint2*>(aux + (int64_t)m * g.ldaux + n) : uint2{0u, 0u};
     }
   };
@@ -1430,9 +1433,10 @@ __device__ __forceinline__ void f8_emit_epilogue(f32x4 (&acc)[8][4], const GemmA
         const bf16x4 u = *reinterpret_cast<const bf16x4*>(&ar[i & 1][j]);
         v[j] = v[j] * dgelu_tanh_f4(f32x4{(float)u[0], (float)u[1], (float)u[2], (float)u[3]});
         o[j] = v[j];
-        if (mok && n < g.N) csum[j] = csum[j] + v[j];
+        if (FULL || (mok && n < g.N)) csum[j] = csum[j] + v[j];
       }
-      if (!(mok && n < g.N)) o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (!FULL)
+        if (!(mok && n < g.N)) o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fabsf(o[j][e]));
       asm volatile("" : "+v"(mx));  // (taken now: left to the optimiser the max chain sank to the end of the tile and o[] was spilled)
@@ -1440,11 +1444,12 @@ __device__ __forceinline__ void f8_emit_epilogue(f32x4 (&acc)[8][4], const GemmA
       const int nl = wn * 64 + 16 * j + 4 * fq;
       *reinterpret_cast<unsigned*>(t_rm + ml * QP + nl) = pk;
       // 4 x 4 byte transpose inside the quad of lanes that holds rows 4 (fr / 4) .. + 3 of these four columns
+      // (quad broadcasts: every lane is written, so there is no "old" value to set up -- update_dpp(0, ..) cost a v_mov per DPP)
       const int pi = (int)pk;
-      const unsigned d0 = (unsigned)__builtin_amdgcn_update_dpp(0, pi, 0x00, 0xF, 0xF, false);
-      const unsigned d1 = (unsigned)__builtin_amdgcn_update_dpp(0, pi, 0x55, 0xF, 0xF, false);
-      const unsigned d2 = (unsigned)__builtin_amdgcn_update_dpp(0, pi, 0xAA, 0xF, 0xF, false);
-      const unsigned d3 = (unsigned)__builtin_amdgcn_update_dpp(0, pi, 0xFF, 0xF, 0xF, false);
+      const unsigned d0 = (unsigned)__builtin_amdgcn_mov_dpp(pi, 0x00, 0xF, 0xF, true);
+      const unsigned d1 = (unsigned)__builtin_amdgcn_mov_dpp(pi, 0x55, 0xF, 0xF, true);
+      const unsigned d2 = (unsigned)__builtin_amdgcn_mov_dpp(pi, 0xAA, 0xF, 0xF, true);
+      const unsigned d3 = (unsigned)__builtin_amdgcn_mov_dpp(pi, 0xFF, 0xF, 0xF, true);
       const unsigned lo = __builtin_amdgcn_perm(d1, d0, sel), hi = __builtin_amdgcn_perm(d3, d2, sel);
       *reinterpret_cast<unsigned*>(t_tr + (nl + kq) * QP + (ml & ~3)) = lo | (hi << 16);
       __builtin_amdgcn_sched_barrier(0);  // (fragment by fragment: the scheduler otherwise kept every o[] alive for the max chain and spilled)
@@ -1459,7 +1464,7 @@ __device__ __forceinline__ void f8_emit_epilogue(f32x4 (&acc)[8][4], const GemmA
         const su32x2 sy = __builtin_amdgcn_permlane16_swap(p0.y, p1.y, false, false);
         const int nb = n_w + 32 * jp;
         const int n = odd ? nb + 16 + 4 * (fq - 1) : nb + 4 * fq;
-        if (mok && n < g.N) {
+        if (FULL || (mok && n < g.N)) {
           const su32x4 ov = su32x4{sx[0], sy[0], sx[1], sy[1]};
           su32x4* ptr = reinterpret_cast<su32x4*>(C + (int64_t)m * g.ldc + n);
           __builtin_nontemporal_store(ov, ptr);  // read again in the backward pass only
@@ -1592,7 +1597,9 @@ __global__ void __launch_bounds__(512, 2) gemm_f8_kernel(const GemmArgs g, const
       }
     }
   } else if constexpr (EMIT) {
-    f8_emit_epilogue<EPI>(acc, g, smem, m0, n0, tid);
+    // (the dGELU form keeps the masked epilogue only: a second copy of it cost that kernel 32 spilled registers)
+    if (EPI == UWU_EPI_BIAS_GELU && g.p8_cont && m0 + 256 <= g.M && n0 + 256 <= g.N) f8_emit_epilogue<EPI, EPI == UWU_EPI_BIAS_GELU>(acc, g, smem, m0, n0, tid);
+    else f8_emit_epilogue<EPI, false>(acc, g, smem, m0, n0, tid);
   } else {
     EpiPre<bf16_t, 8, 4> pre;
     epi_prefetch<bf16_t, 8, 4, EPI>(pre, g, m0 + wm * 128, n0 + wn * 64, fr, fq);
@@ -2099,6 +2106,10 @@ int launch_f8_emit(GemmArgs g, const float* sa, const float* sb, hipStream_t st)
   }
   g.tiles_m = (g.M + 255) / 256;
   g.tiles_n = (g.N + 255) / 256;
+  {
+    static UwuEnv full("UWU_F8_EMIT_FULL");  // "0": the masked epilogue for full tiles too (A/B)
+    g.p8_cont = full.get().is('0') ? 0 : 1;
+  }
   UwuProfScope prof(st);
   hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(512), LDS, st, g, sa, sb);
   // bytes: operands once, the bf16 output (if any), the dGELU aux, both fp8 images

@@ -208,8 +208,10 @@ __global__ void __launch_bounds__(512, 2) gemm_p8f_kernel(const GemmArgs g, cons
       const int m_q = em0 + 128 * x + 64 * grp, n_q = en0 + 128 * y + 32 * wc;
       // (the lane's share of the output addresses is rebuilt here from a lane id hipcc cannot see through: hoisted out of the
       // tile loop, eight copies of this epilogue kept a dozen 64-bit addresses alive across the K loop and spilled them)
+      // (the MFMAs are inline asm: hipcc's hazard recogniser does not know that acc[x][y] is a matrix-pipe result.  Its last
+      // write is at least three phases -- barriers -- back; the wait states make the distance explicit anyway)
       int ln = lane;
-      asm volatile("" : "+v"(ln));
+      asm volatile("s_nop 15\n\ts_nop 15" : "+v"(ln));
       const int fr = ln & 15, fq = ln >> 4;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
