@@ -101,6 +101,9 @@ SDXL_CUT = dict(in_channels=4, out_channels=4, block_out_channels=(320, 640, 128
                 norm_num_groups=32)
 
 
+_ORA_INIT = {}  # seed -> the oracle's initial parameters (unet_models is called four times with two seeds)
+
+
 def unet_models(dtype, seed=0, with_oracle=True):
     from oracle.unet import UNetOracle
     from uwudiff_amd.unet import UNet2DConditionModel
@@ -119,14 +122,19 @@ def unet_models(dtype, seed=0, with_oracle=True):
         for n, f in saved.items():
             setattr(I, n, f)
     with torch.no_grad():  # away from the near-zero init so every branch carries signal
-        for n, p in ora.named_parameters():
-            if p.dim() > 1:
-                p.copy_(torch.randn_like(p) * (0.5 / p[0].numel() ** 0.5))
-            elif n.endswith("bias"):
-                p.copy_(torch.randn_like(p) * 0.05)
-            else:
-                p.copy_(1 + torch.randn_like(p) * 0.1)
-    model = UNet2DConditionModel(SDXL_CUT, compute_dtype=dtype).cuda()
+        if seed in _ORA_INIT:  # (the same 0.9 G draws again: copied instead)
+            for n, p in ora.named_parameters():
+                p.copy_(_ORA_INIT[seed][n])
+        else:
+            for n, p in ora.named_parameters():
+                if p.dim() > 1:
+                    p.copy_(torch.randn_like(p) * (0.5 / p[0].numel() ** 0.5))
+                elif n.endswith("bias"):
+                    p.copy_(torch.randn_like(p) * 0.05)
+                else:
+                    p.copy_(1 + torch.randn_like(p) * 0.1)
+            _ORA_INIT[seed] = {n: p.detach().clone() for n, p in ora.named_parameters()}
+    model = UNet2DConditionModel(SDXL_CUT, compute_dtype=dtype, init_weights=False).cuda()  # (every parameter is loaded next)
     model.load_state_dict(ora.state_dict())
     return ora, model
 
@@ -251,7 +259,7 @@ def test_full_depth_sdxl_unet_properties():
     from uwudiff_amd.unet import UNet2DConditionModel
 
     torch.manual_seed(19)
-    model = UNet2DConditionModel.from_config("sdxl", compute_dtype="bf16").cuda()
+    model = UNet2DConditionModel.from_config("sdxl", compute_dtype="bf16", device="cuda")  # (initial weights drawn on the GPU)
     assert sum(v.numel() for _, v in model.state_dict().items()) == 2_567_463_684
 
     def inputs(B):

@@ -94,10 +94,10 @@ def test_fit_tiny_unet_config_with_clip_and_snr():
 def test_c1_loss_curve_overlay():
     """loss-curve overlay on the plumbing config (tiny UNet, pixels, B=16).  The full 100-step
     curves (tests/loss_curve_overlay.py) are committed as profiles/r01_loss_curve_c1_{fp32,bf16}.csv (max relative
-    deviation 2.9e-6 / 7.7e-3); the suite runs 12 steps to stay fast (the CPU oracle dominates the time)."""
+    deviation 2.9e-6 / 7.7e-3); the suite runs 9 steps to stay fast (the CPU oracle dominates the time)."""
     from tests.loss_curve_overlay import main
 
-    rows, dev = main(steps=12, dtype="fp32")
+    rows, dev = main(steps=9, dtype="fp32")
     assert rows[-1][1] < rows[0][1]          # the oracle's loss goes down
     assert dev < 2e-3, dev                   # HIP fp32 curve tracks it step by step
 
@@ -108,11 +108,11 @@ def test_c2_dit_s2_loss_curve_overlay(dtype, tol):
     the HIP path's per-step loss against the fp32 CPU oracle trained from the same state_dict with the same injected
     (noise, t) stream.  A per-layer error of a few percent -- which the 3e-2 / 6e-2 one-pass tolerances of the bf16 parity tests
     would let through -- moves this curve: the 60-step curves in profiles/r01_loss_curve_c2_dit_s2_*.csv deviate by 7.6e-4
-    (bf16) and 3.5e-7 (fp32) at most; 6 bf16 steps here (the CPU oracle takes 4 s per step; fp32 mode has its own 1e-3
+    (bf16) and 3.5e-7 (fp32) at most; 5 bf16 steps here (the CPU oracle takes 4 s per step; fp32 mode has its own 1e-3
     one-pass parity tests)."""
     from tests.loss_curve_overlay import main_dit
 
-    rows, dev = main_dit(steps=6, dtype=dtype)
+    rows, dev = main_dit(steps=5, dtype=dtype)
     assert rows[-1][1] < rows[0][1]
     assert dev < tol, dev
 

@@ -459,6 +459,12 @@ def sinusoid(t, dim, max_period=10000.0):
 class UNet2DConditionModel(nn.Module):
     def __init__(self, config=None, compute_dtype="bf16", **kw):
         super().__init__()
+        # init_weights=False: leave the flat parameter buffer zero (a state dict is loaded next; the default initialisers draw
+        # 0.9-2.6 G random numbers on the host)
+        init_weights = kw.pop("init_weights", True)
+        # device=...: build the flat parameter buffer there and draw the initial weights with that device's generator (2.6 G
+        # draws of the SDXL shape take half a minute on the host); default: host, as nn.Module constructors do
+        device = kw.pop("device", None)
         cfg = dict(SDXL_UNET_CONFIG)
         cfg.update(config or {})
         cfg.update(kw)
@@ -584,17 +590,21 @@ class UNet2DConditionModel(nn.Module):
         norm("conv_norm_out", boc[0])
         conv("conv_out", boc[0], cfg["out_channels"], cout_store=self.cout_pad)
 
-        self.flat = nn.Parameter(torch.zeros(P.n, dtype=torch.float32))
+        self.flat = nn.Parameter(torch.zeros(P.n, dtype=torch.float32, device=device))
         P.flat = self.flat
         P.bf16 = compute_dtype == "bf16"
         self.register_buffer("shadow", torch.zeros(0, dtype=torch.bfloat16), persistent=False)
-        self.reset_parameters()
+        if init_weights:
+            self.reset_parameters()
+        else:
+            self.refresh_shadow()
 
     # ------------------------------------------------------------------ parameters
     @torch.no_grad()
     def reset_parameters(self):
         """torch default inits per layer type + reference unet_patch.py:34-45 (N(0,1e-5) on residual out layers)."""
-        g = torch.Generator().manual_seed(torch.initial_seed() % (2 ** 31))
+        dev = self.flat.device
+        g = torch.Generator(device=dev).manual_seed(torch.initial_seed() % (2 ** 31))
         zero = self.cfg_dict["zero_init"]
         for name, (off, shape) in self.P.registry.items():
             v = self.P.w32(name)
@@ -610,10 +620,10 @@ class UNet2DConditionModel(nn.Module):
                     cin, cout, ci, co = self._conv_meta[name[:-7]]
                     fan_in = 9 * cin
                 bound = 1.0 / math.sqrt(fan_in)
-                v.copy_((torch.rand(shape, generator=g) * 2 - 1) * bound)
+                v.copy_((torch.rand(shape, generator=g, device=dev) * 2 - 1) * bound)
                 if name.endswith((".conv2.weight", "attn1.to_out.0.weight", "attn2.to_out.0.weight", "ff.net.2.weight",
                                   "conv_out.weight")) and "samplers" not in name:
-                    v.copy_(torch.randn(shape, generator=g) * 1e-5)
+                    v.copy_(torch.randn(shape, generator=g, device=dev) * 1e-5)
                     if zero:  # rope_unet.py:562-580: exact zeros (the biases of these layers are zero already)
                         v.zero_()
         self._zero_padding()
