@@ -26,7 +26,7 @@ def timeit(fn, iters=20, warm=3):
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     which = set(sys.argv[2:])
-    T, D, H, d = 256, 384, 6, 64
+    T, D, H, d = 256, int(os.environ.get("UWU_BENCH_D", "384")), 6, 64  # (UWU_BENCH_D=768 / 1152 with "ln": the wide-row LayerNorm forms)
     M = B * T
     bf = torch.bfloat16
     dev = "cuda"
