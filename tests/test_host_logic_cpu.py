@@ -227,3 +227,26 @@ def test_duwu_utils_import_surface_and_list_helpers(tmp_path):
     assert got == ["a/x.PNG", "a/y.jpeg", "w.gif"]
     with pytest.raises(ValueError):
         U.get_images_recursively(str(tmp_path / "missing"))
+
+
+def test_unet_constructor_options_and_attention_bwd_stride_guard():
+    """Host-side guards added in round 4: `init_weights=False` leaves the flat parameter buffer zero for a state dict to fill (the
+    SDXL-width test pairs are built that way), `device=` places it; `ops.attention_bwd` refuses a gradient whose row stride differs
+    from its tensor's BEFORE any pointer reaches the library (the C ABI has one leading dimension per pair)."""
+    from uwudiff_amd import ops
+    from uwudiff_amd.unet import UNet2DConditionModel
+
+    a = UNet2DConditionModel.from_config("tiny-unet", compute_dtype="fp32")
+    b = UNet2DConditionModel.from_config("tiny-unet", compute_dtype="fp32", init_weights=False, device="cpu")
+    assert float(a.flat.abs().sum()) > 0 and float(b.flat.abs().sum()) == 0 and b.flat.device.type == "cpu"
+    b.load_state_dict(a.state_dict())
+    assert torch.equal(a.flat.data, b.flat.data)
+
+    B, T, H, d = 1, 8, 2, 8
+    D = H * d
+    qkv = torch.zeros(B * T, 3 * D)
+    q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    o, do, lse = torch.zeros(B * T, D), torch.zeros(B * T, D), torch.zeros(B, H, T)
+    dq, dk, dv = (torch.zeros(B * T, D) for _ in range(3))  # contiguous gradients for packed (strided) q / k / v
+    with pytest.raises(ValueError, match="row strides"):
+        ops.attention_bwd(q, k, v, o, do, lse, dq, dk, dv, B, T, T, H, d)
