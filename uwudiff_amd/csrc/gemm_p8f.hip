@@ -317,7 +317,6 @@ __global__ void __launch_bounds__(512, 2) gemm_p8f_kernel(const GemmArgs g, cons
     issue(IC<2>{}, IC<1>{}, 1);
     issue(IC<3>{}, IC<1>{}, 1);
   };
-  int iter = 0;
   auto stamp = [&](int) __attribute__((always_inline)) {};
   auto full_tile = [&]() __attribute__((always_inline)) {
     return !PART && em0 + 256 <= g.M && en0 + 256 <= g.N && g.wide && sizeof(TC) == 2;
@@ -358,7 +357,6 @@ __global__ void __launch_bounds__(512, 2) gemm_p8f_kernel(const GemmArgs g, cons
       s_prev = full_tile() ? NST : 0;
       L = Ln;
       stamp(6);
-      ++iter;
       continue;
     }
     if (grp == 0 && ABL != 3) bar();  // every wave has passed the same number of barriers; nobody reads LDS any more
@@ -377,7 +375,6 @@ __global__ void __launch_bounds__(512, 2) gemm_p8f_kernel(const GemmArgs g, cons
     epi_quadrant(IC<1>{}, IC<1>{});
     epi_quadrant(IC<1>{}, IC<0>{});
     stamp(6);
-    ++iter;
     if (!has_next) break;
     if (!early) {
       setup(tile_of(Ln), m0, n0);
