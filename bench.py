@@ -247,6 +247,7 @@ def main():
     ctx = torch.randn(B, 77, 2048, device=dev) if unet else None  # synthetic text context (77 x 2048)
     time_ids = torch.tensor([[1024.0, 1024, 0, 0, 1024, 1024]] * B, device=dev) if unet else None
     model.flat.grad = torch.zeros_like(model.flat.data)
+    one = torch.ones((), device=dev, dtype=torch.float32)
     step_no = [0]
 
     def step(b=B, sy=None):
@@ -259,7 +260,7 @@ def main():
             loss, _ = loss_fn(x, model, encoder_hidden_states=ctx[:b], added_cond_kwargs={"text_embeds": c, "time_ids": time_ids[:b]})
         else:
             loss, _ = loss_fn(x, model, added_cond_kwargs={"text_embeds": c})
-        loss.backward()
+        loss.backward(one)  # (a resident 1.0: autograd's own ones_like(loss) is a fill launch per step)
         chunks = sy.all_reduce(model.flat.grad)
         opt.param_groups[0]["lr"] = cosine_lr(1e-6, i, 100_000, 1e-7)
         if args.clip > 0:

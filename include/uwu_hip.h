@@ -117,6 +117,9 @@ int uwu_loss_fwd_bwd(const float* x, const float* noise, const float* xt, const 
 
 /* y[i] *= *scale (device scalar); used when autograd hands a non-unit upstream gradient. */
 int uwu_scale_inplace(void* y, int dtype, int64_t n, const float* scale, void* stream);
+/* y[i] = x[i] * *scale: the same for a SAVED gradient that must stay as it is (the loss's d/d(model output), produced in its
+ * forward pass, reference diffusion.py:170-193 via autograd) -- one pass instead of a clone + the in-place form. */
+int uwu_scale_into(const void* x, void* y, int dtype, int64_t n, const float* scale, void* stream);
 
 /* Conditioning front-end (section 8f rank 4): ragged -> padded aggregation of per-caption embeddings.
  * Reference src/duwu/utils/aggregation.py:6-171.  `starts` = device int32 [B+1] prefix sums of n_elements; one "unit"

@@ -496,6 +496,26 @@ extern "C" int uwu_loss_fwd_bwd(const float* x, const float* noise, const float*
   return UWU_OK;
 }
 
+template <typename T>
+__global__ void scale_into_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n4, const float* __restrict__ scale) {
+  const float s = scale[0];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) store4(y + 4 * i, load4(x + 4 * i) * s);
+}
+
+extern "C" int uwu_scale_into(const void* x, void* y, int dtype, int64_t n, const float* scale, void* stream) {
+  UWU_CHECK_ARG(x && y && scale && n > 0 && n % 4 == 0, "scale_into: bad args (n=%lld)", (long long)n);
+  UWU_CHECK_ARG(dtype == UWU_F32 || dtype == UWU_BF16, "scale_into: bad dtype %d", dtype);
+  if (dtype == UWU_F32)
+    hipLaunchKernelGGL((scale_into_kernel<float>), dim3(ew_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                       (float*)y, n / 4, scale);
+  else
+    hipLaunchKernelGGL((scale_into_kernel<bf16_t>), dim3(ew_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (bf16_t*)y, n / 4, scale);
+  UWU_LAUNCH_CHECK("scale_into");
+  return UWU_OK;
+}
+
 extern "C" int uwu_scale_inplace(void* y, int dtype, int64_t n, const float* scale, void* stream) {
   UWU_CHECK_ARG(y && scale && n > 0 && n % 4 == 0, "scale_inplace: bad args (n=%lld)", (long long)n);
   if (dtype == UWU_F32)

@@ -261,6 +261,7 @@ class Fitter:
         self.current_epoch = epoch
         self.batches_in_epoch = resume_skip
         grads_zeroed = False
+        one = None
         while not done:
             finished_epoch, ran = True, 0
             for bi, batch in enumerate(loader):
@@ -276,7 +277,9 @@ class Fitter:
                             p.grad.zero_()
                 out = module.training_step(self._to_device(batch), self.global_step)
                 loss = out["loss"]
-                loss.backward()
+                if one is None or one.device != loss.device or one.dtype != loss.dtype:
+                    one = torch.ones_like(loss)  # (kept: autograd's own ones_like(loss) is a fill launch per step)
+                loss.backward(one)
                 clip = None
                 if isinstance(opt, FusedAdamW):
                     chunks = sync.all_reduce(params[0].grad)

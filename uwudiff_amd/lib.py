@@ -55,6 +55,7 @@ _SIGS = {
     "uwu_ctx_place": (c_int, [P, c_int, P, P] + [c_int] * 7 + [P]),
     "uwu_loss_fwd_bwd": (c_int, [P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int64, P, P, P, P, P, P]),
     "uwu_scale_inplace": (c_int, [P, c_int, c_int64, P, P]),
+    "uwu_scale_into": (c_int, [P, P, c_int, c_int64, P, P]),
     "uwu_sampler_step": (c_int, [P, P, P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, P]),
     "uwu_aggregate_concat": (c_int, [P, P, P, c_int, c_int, c_int64, c_int, ctypes.c_uint64, P]),
     "uwu_aggregate_split": (c_int, [P, P, P, c_int, c_int, c_int64, P]),

@@ -55,16 +55,19 @@ class _FusedLoss(torch.autograd.Function):
         ctx.save_for_backward(grad)
         ctx.out_dtype = model_output.dtype
         ctx.mark_non_differentiable(losses, pred, target)
+        ctx.set_materialize_grads(False)  # (autograd otherwise fills a zero gradient for each of the three outputs nobody differentiates)
         return loss, losses, pred, target
 
     @staticmethod
     def backward(ctx, g_loss, *_):
         (saved,) = ctx.saved_tensors
+        if g_loss is None:  # (materialize_grads is off: nobody asked for d loss)
+            return (None,) * 8
         g = g_loss.to(device=saved.device, dtype=torch.float32).contiguous()
-        # scale a copy: a second backward through the same graph (retain_graph / accumulation helpers) must see the
+        # scaled INTO a new tensor: a second backward through the same graph (retain_graph / accumulation helpers) must see the
         # unscaled gradient again, and the returned tensor must not alias the saved one
-        grad = saved.clone()
-        L.call("uwu_scale_inplace", L.ptr(grad), L.dt(grad), grad.numel(), L.ptr(g), L.stream())
+        grad = torch.empty_like(saved)
+        L.call("uwu_scale_into", L.ptr(saved), L.ptr(grad), L.dt(grad), grad.numel(), L.ptr(g), L.stream())
         if grad.dtype != ctx.out_dtype:
             grad = grad.to(ctx.out_dtype)
         return grad, None, None, None, None, None, None, None
