@@ -54,6 +54,9 @@ int uwu_version(void);
 /* The library's environment switches (UWU_GEMM_*, ...: kernel A/B comparisons and sweeps, tools/README.md) are read once
  * and cached; call this after changing one inside a running process.  Returns the new generation number. */
 int uwu_env_refresh(void);
+/* Zero `bytes` bytes of device memory on `stream` (hipMemsetAsync): the flat gradient buffer and the optimizer moments at their
+ * creation (reference: torch.zeros_like in torch.optim.AdamW's state initialisation / autograd's first accumulation). */
+int uwu_memset_zero(void* p, uint64_t bytes, void* stream);
 
 /* ------------------------------------------------------------------ objective (a1-a10) */
 
@@ -120,6 +123,9 @@ int uwu_scale_inplace(void* y, int dtype, int64_t n, const float* scale, void* s
 /* y[i] = x[i] * *scale: the same for a SAVED gradient that must stay as it is (the loss's d/d(model output), produced in its
  * forward pass, reference diffusion.py:170-193 via autograd) -- one pass instead of a clone + the in-place form. */
 int uwu_scale_into(const void* x, void* y, int dtype, int64_t n, const float* scale, void* stream);
+/* y[i] = (float)x[i] for the int64 timesteps the loss hands the denoiser (reference diffusion.py:68-70 draws them as int64,
+ * rope_unet.py / the DiT's timestep embedding reads them as floats): the conversion in front of the forward, on the library's stream. */
+int uwu_cast_i64_to_f32(const int64_t* x, float* y, int64_t n, void* stream);
 
 /* Conditioning front-end (section 8f rank 4): ragged -> padded aggregation of per-caption embeddings.
  * Reference src/duwu/utils/aggregation.py:6-171.  `starts` = device int32 [B+1] prefix sums of n_elements; one "unit"

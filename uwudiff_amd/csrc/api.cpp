@@ -22,6 +22,18 @@ static int g_env_gen = 0;
 int uwu_env_generation() { return g_env_gen; }
 extern "C" int uwu_env_refresh(void) { return ++g_env_gen; }
 
+extern "C" int uwu_memset_zero(void* p, uint64_t bytes, void* stream) {
+  if (!p || !bytes) {
+    uwu_set_error("memset_zero: bad argument");
+    return UWU_EINVAL;
+  }
+  if (hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream) != hipSuccess) {
+    uwu_set_error("memset_zero: hipMemsetAsync failed");
+    return UWU_ELAUNCH;
+  }
+  return UWU_OK;
+}
+
 // ---- per-device facts for the kernels that own a whole CU (persistent grids, > 64 KB of dynamic LDS) -------------------------
 // Cached PER DEVICE: a process may drive several GPUs (a function-local `static once` applied the first device's CU
 // count and LDS attribute to every later device).

@@ -503,6 +503,18 @@ __global__ void scale_into_kernel(const T* __restrict__ x, T* __restrict__ y, in
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) store4(y + 4 * i, load4(x + 4 * i) * s);
 }
 
+__global__ void cast_i64_f32_kernel(const int64_t* __restrict__ x, float* __restrict__ y, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = (float)x[i];
+}
+
+extern "C" int uwu_cast_i64_to_f32(const int64_t* x, float* y, int64_t n, void* stream) {
+  UWU_CHECK_ARG(x && y && n > 0, "cast_i64_to_f32: bad args (n=%lld)", (long long)n);
+  hipLaunchKernelGGL(cast_i64_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+  UWU_LAUNCH_CHECK("cast_i64_to_f32");
+  return UWU_OK;
+}
+
 extern "C" int uwu_scale_into(const void* x, void* y, int dtype, int64_t n, const float* scale, void* stream) {
   UWU_CHECK_ARG(x && y && scale && n > 0 && n % 4 == 0, "scale_into: bad args (n=%lld)", (long long)n);
   UWU_CHECK_ARG(dtype == UWU_F32 || dtype == UWU_BF16, "scale_into: bad dtype %d", dtype);

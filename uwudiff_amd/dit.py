@@ -336,7 +336,8 @@ class DiT(nn.Module):
 
     def _run_backward(self, dout, cond):
         if self.flat.grad is None:
-            self.flat.grad = torch.zeros_like(self.flat.data)
+            self.flat.grad = torch.empty_like(self.flat.data)
+            L.call("uwu_memset_zero", L.ptr(self.flat.grad), self.flat.grad.numel() * 4, L.stream())
         d = self._descriptor(dout.shape[0])
         d.fp8 = getattr(self, "_f8_mode", 0)  # the backward uses the scaling policy its forward used
         L.call("uwu_dit_backward", ctypes.byref(d), L.ptr(dout), L.stream())
@@ -353,7 +354,12 @@ class DiT(nn.Module):
         noisy = sample.float().contiguous()
         if not torch.is_tensor(timestep):
             timestep = torch.tensor([timestep], device=sample.device)
-        t = timestep.to(device=sample.device, dtype=torch.float32).reshape(-1)
+        if timestep.dtype == torch.int64 and timestep.is_cuda and timestep.device == sample.device and timestep.is_contiguous():
+            t = torch.empty(timestep.shape, device=sample.device, dtype=torch.float32)  # (the loss draws int64 timesteps)
+            L.call("uwu_cast_i64_to_f32", L.ptr(timestep), L.ptr(t), timestep.numel(), L.stream())
+            t = t.reshape(-1)
+        else:
+            t = timestep.to(device=sample.device, dtype=torch.float32).reshape(-1)
         if t.numel() == 1 and B > 1:
             t = t.expand(B)
         t = t.contiguous()

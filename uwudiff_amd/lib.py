@@ -43,6 +43,7 @@ _SIGS = {
     "uwu_last_error": (c_char_p, []),
     "uwu_version": (c_int, []),
     "uwu_env_refresh": (c_int, []),
+    "uwu_memset_zero": (c_int, [P, ctypes.c_uint64, P]),
     "uwu_schedule_gather": (c_int, [P, P, P, P, c_int, c_int, c_int, c_float, c_int, P, P]),
     "uwu_rf_time_to_sigma": (c_int, [P, c_float, P, c_int, c_int, P, P, P]),
     "uwu_qsample": (c_int, [P, P, P, c_int, c_int64, P, P, P]),
@@ -56,6 +57,7 @@ _SIGS = {
     "uwu_loss_fwd_bwd": (c_int, [P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int64, P, P, P, P, P, P]),
     "uwu_scale_inplace": (c_int, [P, c_int, c_int64, P, P]),
     "uwu_scale_into": (c_int, [P, P, c_int, c_int64, P, P]),
+    "uwu_cast_i64_to_f32": (c_int, [P, P, c_int64, P]),
     "uwu_sampler_step": (c_int, [P, P, P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, P]),
     "uwu_aggregate_concat": (c_int, [P, P, P, c_int, c_int, c_int64, c_int, ctypes.c_uint64, P]),
     "uwu_aggregate_split": (c_int, [P, P, P, c_int, c_int, c_int64, P]),

@@ -12,6 +12,15 @@ import torch
 from . import lib as L
 
 
+def _zeros_like(t):
+    """torch.zeros_like for the flat buffers; on the HIP device the fill is the library's (hipMemsetAsync on the current stream)."""
+    if not (t.is_cuda and t.is_contiguous()):
+        return torch.zeros_like(t)
+    z = torch.empty_like(t)
+    L.call("uwu_memset_zero", L.ptr(z), z.numel() * z.element_size(), L.stream())
+    return z
+
+
 class FusedAdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
@@ -53,8 +62,8 @@ class FusedAdamW(torch.optim.Optimizer):
                 st = self.state[p]
                 if not st:
                     st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p.data)
-                    st["exp_avg_sq"] = torch.zeros_like(p.data)
+                    st["exp_avg"] = _zeros_like(p.data)
+                    st["exp_avg_sq"] = _zeros_like(p.data)
                 st["step"] += 1
                 shadow = getattr(p, "_uwu_bf16_shadow", None)
                 if shadow is not None and shadow.numel() != p.numel():
